@@ -1,0 +1,334 @@
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 on 32x32 MFMA tiles.
+//
+// GEMM view:  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],  k = (tap, cin).
+// The A operand is the packed weight block (32 couts x 16 cin of one tap), the
+// B operand 32 output pixels x the same 16 cin read from an LDS halo tile at the
+// tap's (dy,dx) shift -- no im2col buffer exists.  Activations live in the C8
+// layout ([B][C/8][H][W][8]), so a 16-channel K step is two octet planes and
+// every LDS fragment read is one 16-byte slot per lane.
+//
+// One workgroup = 4 waves = (4*RW) groups of 32 output pixels x (32*NB) couts.
+// K loop over 16-channel chunks, register-staged double buffering: the global
+// loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
+// other LDS stage afterwards (one barrier per chunk).
+//
+// Epilogue (bias, derivative mask, LeakyReLU/ReLU, residual scaling, optional
+// PixelShuffle(2) scatter) runs on the accumulators; the weight packer orders
+// the 32 rows of a block so each lane's registers 0..7 / 8..15 are two whole
+// output octets, stored with 16-byte writes and no cross-lane traffic.
+#include "srx_common.h"
+
+namespace {
+
+struct ConvParams {
+  const void* x; long x_is;
+  void* y; long y_is;
+  const void* w; const float* bias;
+  const void* res1; long r1_is;
+  const void* res2; long r2_is;
+  const void* mask; long m_is;
+  float alpha, beta1, beta2, act_slope, mask_slope;
+  int H, W, OH, OW;
+  int cin8, cout8, nchunk, nblk, ngroups;
+  int tiles_x, tiles_y;
+  int ps;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x8 type; };
+
+__device__ __forceinline__ void mma(const bf16x8& a, const bf16x8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+}
+
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int TW = 1 << LTW;
+  constexpr int RPG = 32 >> LTW;            // rows per 32-pixel group
+  constexpr int TH = 4 * RW * RPG;
+  constexpr int PAD = KS / 2;
+  constexpr int TAPS = KS * KS;
+  constexpr int IH = (TH - 1) * STRIDE + KS;
+  constexpr int IW = (TW - 1) * STRIDE + KS;
+  constexpr int NPIX = IH * IW;
+  constexpr int PPO = Oct<T>::PPO;
+  constexpr int EPP = 16 / sizeof(T);       // elements per 16-byte piece
+  constexpr int XP = 2 * NPIX * PPO;
+  constexpr int WP = NB * TAPS * 64 * PPO;
+  constexpr int NXS = (XP + 255) / 256;
+  constexpr int NWS = (WP + 255) / 256;
+  constexpr int STAGE = XP + WP;            // pieces per stage
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int pl = lane & 31;                 // pixel / row index inside the MFMA tile
+  const int hh = lane >> 5;                 // k half
+
+  int bid = blockIdx.x;
+  const int grp = bid % p.ngroups; bid /= p.ngroups;
+  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int nb0 = grp * NB;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+  const long plane_in = (long)p.H * p.W * 8;
+
+  const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
+  const T* wb = reinterpret_cast<const T*>(p.w);
+
+  // ---- per-thread staging plan (independent of the chunk) ----
+  int xoff[NXS];
+  unsigned xok = 0, xh1 = 0;                // validity / "second octet" bitmasks
+#pragma unroll
+  for (int i = 0; i < NXS; ++i) {
+    int piece = tid + i * 256;
+    int q = piece % PPO;
+    int pix = (piece / PPO) % NPIX;
+    int h = piece / (PPO * NPIX);
+    int r = pix / IW, c = pix % IW;
+    int gy = iy0 + r, gx = ix0 + c;
+    bool ok = piece < XP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    xoff[i] = ok ? (int)(h * plane_in + ((long)gy * p.W + gx) * 8 + q * EPP) : 0;
+    if (ok) xok |= 1u << i;
+    if (h) xh1 |= 1u << i;
+  }
+
+  uint4 xr[NXS], wr[NWS];
+  auto load_regs = [&](int chunk) {
+    const T* xc = xb + (long)chunk * 2 * plane_in;
+    const bool has_h1 = chunk * 2 + 1 < p.cin8;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      bool ok = (xok >> i) & 1;
+      if (((xh1 >> i) & 1) && !has_h1) ok = false;
+      xr[i] = ok ? *reinterpret_cast<const uint4*>(xc + xoff[i]) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+      int piece = tid + i * 256;
+      if (piece < WP) {
+        int nb = piece / (TAPS * 64 * PPO);
+        int rem = piece % (TAPS * 64 * PPO);
+        const T* src = wb + ((long)(nb0 + nb) * p.nchunk + chunk) * (TAPS * 512) + rem * EPP;
+        wr[i] = *reinterpret_cast<const uint4*>(src);
+      }
+    }
+  };
+  auto store_lds = [&](int stage) {
+    uint4* sx = smem + stage * STAGE;
+    uint4* sw = sx + XP;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      int piece = tid + i * 256;
+      if (piece < XP) sx[piece] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+      int piece = tid + i * 256;
+      if (piece < WP) sw[piece] = wr[i];
+    }
+  };
+
+  f32x16 acc[RW][NB];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][n][i] = 0.f;
+
+  // LDS slot (in octets) of this lane's pixel for row group rg at tap (0,0)
+  int xslot[RW];
+#pragma unroll
+  for (int rg = 0; rg < RW; ++rg) {
+    int g = wave * RW + rg;
+    int py = g * RPG + (pl >> LTW), px = pl & (TW - 1);
+    xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
+  }
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    const int stage = chunk & 1;
+    if (chunk + 1 < p.nchunk) load_regs(chunk + 1);
+    const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
+    const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XP);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = tap / KS, dx = tap % KS;
+      frag_t wf[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) wf[n] = sw[((n * TAPS + tap) * 2 + hh) * 32 + pl];
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg) {
+        frag_t xf = sx[xslot[rg] + dy * IW + dx];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) mma(wf[n], xf, acc[rg][n]);
+      }
+    }
+    if (chunk + 1 < p.nchunk) store_lds(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const long plane_out = (long)p.OH * p.OW * 8;
+#pragma unroll
+  for (int rg = 0; rg < RW; ++rg) {
+    const int g = wave * RW + rg;
+    const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
+    if (oy >= p.OH || ox >= p.OW) continue;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int nb = nb0 + n;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
+        if (p.bias) {
+          const float* bp = p.bias + (nb * 2 + hh) * 16 + j * 8;
+          f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
+          f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (p.ps) {
+          if (nb >= p.cout8) continue;
+          T* yp = reinterpret_cast<T*>(p.y) + (long)b * p.y_is + (long)nb * 4 * plane_out +
+                  ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox + j) * 8;
+          if (p.act_slope != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
+          }
+          store_oct(yp, v);
+        } else {
+          const int oct = nb * 4 + 2 * j + hh;
+          if (oct >= p.cout8) continue;
+          const long off = (long)oct * plane_out + ((long)oy * p.OW + ox) * 8;
+          if (p.mask) {
+            float m[8];
+            load_oct(reinterpret_cast<const T*>(p.mask) + (long)b * p.m_is + off, m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
+          }
+          if (p.act_slope != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
+          }
+          if (p.alpha != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          }
+          if (p.res1) {
+            float r[8];
+            load_oct(reinterpret_cast<const T*>(p.res1) + (long)b * p.r1_is + off, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.beta1 * r[e];
+          }
+          if (p.res2) {
+            float r[8];
+            load_oct(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is + off, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.beta2 * r[e];
+          }
+          store_oct(reinterpret_cast<T*>(p.y) + (long)b * p.y_is + off, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
+int launch(const ConvParams& p0, int B, hipStream_t stream) {
+  constexpr int TW = 1 << LTW;
+  constexpr int TH = 4 * RW * (32 >> LTW);
+  constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+  constexpr int PPO = Oct<T>::PPO;
+  constexpr int STAGE = 2 * IH * IW * PPO + NB * KS * KS * 64 * PPO;
+  constexpr int LDS = 2 * STAGE * 16;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  ConvParams p = p0;
+  p.tiles_x = (p.OW + TW - 1) / TW;
+  p.tiles_y = (p.OH + TH - 1) / TH;
+  p.ngroups = p.nblk / NB;
+  auto kern = conv_kernel<T, STRIDE, NB, RW, LTW, KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  long grid = (long)p.tiles_x * p.tiles_y * B * p.ngroups;
+  SRX_CHECK_ARG(grid > 0 && grid < (1L << 31), "conv grid out of range");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+  return srx_check_launch("conv_kernel");
+}
+
+template <typename T>
+int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
+  const bool nb2 = (p.nblk % 2) == 0;
+  if (d->ksize == 1) {
+    return nb2 ? launch<T, 1, 2, 1, 5, 1>(p, d->B, s) : launch<T, 1, 1, 1, 5, 1>(p, d->B, s);
+  }
+  if (d->stride == 1) {
+    if (p.OW >= 24) {
+      if (p.OH * p.OW >= 128 * 128 && !nb2) return launch<T, 1, 1, 4, 5, 3>(p, d->B, s);
+      return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
+    }
+    if (p.OW >= 12) return nb2 ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);
+    return nb2 ? launch<T, 1, 2, 1, 3, 3>(p, d->B, s) : launch<T, 1, 1, 1, 3, 3>(p, d->B, s);
+  }
+  if (p.OW >= 24) return nb2 ? launch<T, 2, 2, 1, 5, 3>(p, d->B, s) : launch<T, 2, 1, 1, 5, 3>(p, d->B, s);
+  if (p.OW >= 12) return nb2 ? launch<T, 2, 2, 1, 4, 3>(p, d->B, s) : launch<T, 2, 1, 1, 4, 3>(p, d->B, s);
+  return nb2 ? launch<T, 2, 2, 1, 3, 3>(p, d->B, s) : launch<T, 2, 1, 1, 3, 3>(p, d->B, s);
+}
+
+}  // namespace
+
+extern "C" int srx_conv2d(const srx_conv_desc* d, void* stream) {
+  SRX_CHECK_ARG(d != nullptr, "srx_conv2d: null descriptor");
+  SRX_CHECK_ARG(d->dtype == SRX_BF16 || d->dtype == SRX_F32, "srx_conv2d: bad dtype %d", d->dtype);
+  SRX_CHECK_ARG(d->ksize == 3 || d->ksize == 1, "srx_conv2d: ksize must be 3 or 1 (got %d)", d->ksize);
+  SRX_CHECK_ARG(d->stride == 1 || (d->stride == 2 && d->ksize == 3),
+                "srx_conv2d: stride must be 1, or 2 with ksize 3 (got %d)", d->stride);
+  SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0,
+                "srx_conv2d: non-positive size B=%d H=%d W=%d cin=%d cout=%d", d->B, d->H, d->W, d->cin, d->cout);
+  SRX_CHECK_ARG(d->x && d->y && d->w, "srx_conv2d: null x/y/w pointer");
+  SRX_CHECK_ARG(!d->pixel_shuffle || (d->cout % 32 == 0 && !d->mask && !d->res1 && !d->res2 && d->alpha == 1.f),
+                "srx_conv2d: pixel_shuffle needs cout %% 32 == 0 and no mask/residual/alpha");
+  SRX_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w) % 16 == 0,
+                "srx_conv2d: x/y/w must be 16-byte aligned");
+  ConvParams p;
+  p.x = d->x; p.x_is = d->x_img_stride;
+  p.y = d->y; p.y_is = d->y_img_stride;
+  p.w = d->w; p.bias = d->bias;
+  p.res1 = d->res1; p.r1_is = d->res1_img_stride;
+  p.res2 = d->res2; p.r2_is = d->res2_img_stride;
+  p.mask = d->mask; p.m_is = d->mask_img_stride;
+  p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2;
+  p.act_slope = d->act_slope; p.mask_slope = d->mask_slope;
+  p.H = d->H; p.W = d->W;
+  const int pad = d->ksize / 2;
+  p.OH = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+  p.OW = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+  p.cin8 = (d->cin + 7) / 8;
+  p.nchunk = (d->cin + 15) / 16;
+  p.nblk = (d->cout + 31) / 32;
+  p.cout8 = d->pixel_shuffle ? d->cout / 32 : (d->cout + 7) / 8;
+  p.ps = d->pixel_shuffle;
+  p.tiles_x = p.tiles_y = p.ngroups = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == SRX_BF16 ? dispatch<bf16>(d, p, s) : dispatch<float>(d, p, s);
+}

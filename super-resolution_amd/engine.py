@@ -1,0 +1,644 @@
+"""Host-side execution plans for the ESRGAN hot path.
+
+A *plan* is built once per (module, batch shape, dtype, grad-mode).  It owns the
+C8 activation buffers, the packed-weight buffers and three recorded op lists
+(forward, backward, weight-packing) whose descriptors hold raw device pointers;
+running a plan is one ``srx_run_ops`` call per phase.  PyTorch supplies device
+memory and the stream; all arithmetic runs in libsrx (HIP).
+
+Dense blocks (esrgan/generator.py:6-23) are executed without concatenation:
+each block owns one (nf+4*gc)-channel buffer; convolution k reads channel
+planes [0, nf+(k-1)gc) and writes planes [nf+(k-1)gc, nf+k*gc); conv5 writes
+``0.2*y + x`` straight into the next block's first nf planes.
+
+The data gradient of a dense block is run as the mirror image: a "gradient
+buffer" [gy1|gy2|gy3|gy4|g_out] per block, where the gradient of growth slice
+j is ONE convolution over the planes [gy_{j+1} .. g_out] with the stacked,
+transposed, tap-flipped weights of convolutions j+1..5 (so no read-modify-write
+accumulation is needed), masked by LeakyReLU'(x_j) from the saved forward
+buffer.  Weight gradients of the five convolutions are one launch per block.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+LRELU = 0.2
+RES = 0.2
+
+
+def _ceil(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+def dtype_id(t: torch.dtype) -> int:
+    if t == torch.bfloat16:
+        return L.BF16
+    if t == torch.float32:
+        return L.F32
+    raise ValueError(f"compute dtype must be torch.bfloat16 or torch.float32, got {t}")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Buf:
+    """A C8 activation buffer [B][C8][H][W][8]."""
+
+    def __init__(self, B: int, C_: int, H: int, W: int, tdtype, device, zero: bool = False):
+        self.B, self.C, self.H, self.W = B, C_, H, W
+        self.C8 = _ceil(C_, 8)
+        self.plane = H * W * 8
+        self.img_stride = self.C8 * self.plane
+        n = B * self.img_stride
+        self.t = (torch.zeros if zero else torch.empty)(n, dtype=tdtype, device=device)
+        self.esize = self.t.element_size()
+
+    def ptr(self, oct0: int = 0) -> int:
+        return self.t.data_ptr() + oct0 * self.plane * self.esize
+
+    @property
+    def nbytes(self) -> int:
+        return self.t.numel() * self.esize
+
+
+View = Tuple[Buf, int]   # (buffer, first octet plane)
+
+
+class Plan:
+    """Recorder of ops + owner of buffers.  Subclasses build the op lists."""
+
+    def __init__(self, device, tdtype):
+        if device.type != "cuda":
+            raise RuntimeError("libsrx plans run on a ROCm device only (got %s); there is no CPU path" % device)
+        self.device = device
+        self.tdtype = tdtype
+        self.dt = dtype_id(tdtype)
+        self.esize = 2 if self.dt == L.BF16 else 4
+        self.lib = L.lib()
+        self.keep: List[torch.Tensor] = []
+        self.pack_layers: List[L.PackLayer] = []
+        self.pack_segs: List[L.PackSeg] = []
+        self.pack_scale_ptrs: List[int] = []
+        self.pack_max_elems = 0
+        self._pack_dev = None
+        self.unpack_items: List[L.UnpackItem] = []
+        self.unpack_max = 0
+        self._unpack_dev = None
+        self.bytes_alloc = 0
+
+    # ------------------------------------------------------------ memory
+    def buf(self, B, C_, H, W, zero=False) -> Buf:
+        b = Buf(B, C_, H, W, self.tdtype, self.device, zero)
+        self.bytes_alloc += b.nbytes
+        return b
+
+    def f32(self, n: int, zero=True) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        self.bytes_alloc += t.numel() * 4
+        return t
+
+    def upload(self, arr) -> torch.Tensor:
+        """Copy a ctypes array to the device; returns the owning uint8 tensor."""
+        raw = C.string_at(C.addressof(arr), C.sizeof(arr))
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.keep.append(t)
+        return t
+
+    # ----------------------------------------------------------- packing
+    def packed_layer(self, cout: int, cin: int, taps: int, perm: int,
+                     segs: Sequence[dict], bias_ptr: int = 0, with_bias: bool = True):
+        """Register a virtual conv layer to pack; returns (w_ptr, bias_ptr)."""
+        nblk, nchunk = _ceil(cout, 32), _ceil(cin, 16)
+        nel = nblk * nchunk * taps * 512
+        w = torch.empty(nel, dtype=self.tdtype, device=self.device)
+        self.keep.append(w)
+        self.bytes_alloc += nel * self.esize
+        bias = None
+        if with_bias:
+            bias = self.f32(nblk * 32)
+        lay = L.PackLayer()
+        lay.dst_w = w.data_ptr()
+        lay.dst_bias = bias.data_ptr() if bias is not None else None
+        lay.src_bias = bias_ptr or None
+        lay.cout, lay.cin, lay.nblk, lay.nchunk, lay.taps, lay.perm = cout, cin, nblk, nchunk, taps, perm
+        lay.seg_begin, lay.seg_count = len(self.pack_segs), len(segs)
+        for s in segs:
+            ps = L.PackSeg()
+            ps.src = s["src"]
+            ps.cin_src, ps.cout_src = s["cin_src"], s["cout_src"]
+            ps.c_begin, ps.c_count = s["c_begin"], s["c_count"]
+            ps.src_off, ps.src_o_off = s.get("src_off", 0), s.get("src_o_off", 0)
+            ps.transposed = s.get("transposed", 0)
+            ps.scale = s.get("scale", 1.0)
+            self.pack_segs.append(ps)
+            self.pack_scale_ptrs.append(s.get("scale_ptr", 0))
+        self.pack_layers.append(lay)
+        self.pack_max_elems = max(self.pack_max_elems, nel)
+        return w.data_ptr(), (bias.data_ptr() if bias is not None else 0)
+
+    def finalize_packing(self):
+        if not self.pack_layers:
+            return
+        la = (L.PackLayer * len(self.pack_layers))(*self.pack_layers)
+        sa = (L.PackSeg * len(self.pack_segs))(*self.pack_segs)
+        pa = (C.c_void_p * len(self.pack_scale_ptrs))(*[p or None for p in self.pack_scale_ptrs])
+        self._pack_dev = (self.upload(la), self.upload(sa), self.upload(pa))
+        self._pack_scaled = any(self.pack_scale_ptrs)
+
+    def run_packing(self):
+        if self._pack_dev is None:
+            return
+        la, sa, pa = self._pack_dev
+        rc = self.lib.srx_pack_weights_scaled(self.dt, la.data_ptr(), sa.data_ptr(),
+                                              pa.data_ptr() if self._pack_scaled else None,
+                                              len(self.pack_layers), self.pack_max_elems,
+                                              stream_ptr(self.device))
+        L.check(rc, "srx_pack_weights")
+
+    # --------------------------------------------------------------- ops
+    def conv(self, ops: list, x: View, y: View, w_ptr: int, bias_ptr: int, B: int, H: int, W: int,
+             cin: int, cout: int, *, ksize=3, stride=1, act=1.0, alpha=1.0, ps=0,
+             mask: Optional[View] = None, mask_slope=0.0,
+             res1: Optional[View] = None, beta1=1.0, res2: Optional[View] = None, beta2=1.0):
+        op = L.Op()
+        op.kind = L.OP_CONV
+        d = op.u.conv
+        d.dtype, d.ksize, d.stride = self.dt, ksize, stride
+        d.B, d.H, d.W, d.cin, d.cout, d.pixel_shuffle = B, H, W, cin, cout, ps
+        d.x, d.x_img_stride = x[0].ptr(x[1]), x[0].img_stride
+        d.y, d.y_img_stride = y[0].ptr(y[1]), y[0].img_stride
+        d.w, d.bias = w_ptr, (bias_ptr or None)
+        d.act_slope, d.alpha = act, alpha
+        if mask is not None:
+            d.mask, d.mask_img_stride, d.mask_slope = mask[0].ptr(mask[1]), mask[0].img_stride, mask_slope
+        if res1 is not None:
+            d.res1, d.res1_img_stride, d.beta1 = res1[0].ptr(res1[1]), res1[0].img_stride, beta1
+        if res2 is not None:
+            d.res2, d.res2_img_stride, d.beta2 = res2[0].ptr(res2[1]), res2[0].img_stride, beta2
+        ops.append(op)
+
+    def generic(self, ops: list, kind: int, *, a: Optional[View] = None, b: Optional[View] = None,
+                c: Optional[View] = None, c_ptr: int = 0, mask: Optional[View] = None,
+                B=0, C_=0, H=0, W=0, noct=0, f0=0.0, f1=0.0, n=0):
+        op = L.Op()
+        op.kind = kind
+        g = op.u.g
+        g.dtype, g.B, g.C, g.H, g.W, g.noct = self.dt, B, C_, H, W, noct
+        if a is not None:
+            g.a, g.a_img_stride = a[0].ptr(a[1]), a[0].img_stride
+        if b is not None:
+            g.b, g.b_img_stride = b[0].ptr(b[1]), b[0].img_stride
+        if c is not None:
+            g.c, g.c_img_stride = c[0].ptr(c[1]), c[0].img_stride
+        elif c_ptr:
+            g.c = c_ptr
+        if mask is not None:
+            g.mask, g.mask_img_stride = mask[0].ptr(mask[1]), mask[0].img_stride
+        g.f0, g.f1, g.n = f0, f1, n
+        ops.append(op)
+
+    def memset(self, ops: list, t: torch.Tensor):
+        self.generic(ops, L.OP_MEMSET, c_ptr=t.data_ptr(), n=t.numel() * t.element_size())
+
+    # ------------------------------------------------------------- wgrad
+    @staticmethod
+    def wgrad_tasks_for_layer(cin: int, cout: int, x_oct0: int, gy_oct0: int, out_ptr: int,
+                              scale: float = 1.0) -> List[dict]:
+        """64x64 block tasks of one convolution's weight gradient.
+        out_ptr: tap-major fp32 [taps][cout][cin] tensor."""
+        tasks = []
+        for cj in range(_ceil(cout, 64)):
+            for ci in range(_ceil(cin, 64)):
+                t = {"x_oct": x_oct0 + ci * 8, "gy_oct": gy_oct0 + cj * 8,
+                     "x_noct": min(8, _ceil(cin, 8) - ci * 8), "gy_noct": min(8, _ceil(cout, 8) - cj * 8),
+                     "sub": {}}
+                for a in (0, 1):
+                    for b in (0, 1):
+                        ci0, co0 = ci * 64 + a * 32, cj * 64 + b * 32
+                        if ci0 < cin and co0 < cout:
+                            t["sub"][a + 2 * b] = dict(out=out_ptr, ld=cin, co_n=cout, ci0=ci0, co0=co0,
+                                                       scale=scale)
+                tasks.append(t)
+        return tasks
+
+    @staticmethod
+    def merge_tasks(tasks: List[dict]) -> List[dict]:
+        merged: Dict[Tuple[int, int], List[dict]] = {}
+        for t in tasks:
+            lst = merged.setdefault((t["x_oct"], t["gy_oct"]), [])
+            for m in lst:
+                if not (set(m["sub"]) & set(t["sub"])):
+                    m["sub"].update(t["sub"])
+                    m["x_noct"] = max(m["x_noct"], t["x_noct"])
+                    m["gy_noct"] = max(m["gy_noct"], t["gy_noct"])
+                    break
+            else:
+                lst.append({**t, "sub": dict(t["sub"])})
+        return [m for lst in merged.values() for m in lst]
+
+    def wgrad(self, ops: list, x: View, gy: View, tasks: List[dict], B: int, H: int, W: int, *,
+              ksize=3, stride=1, target_blocks=512):
+        arr = (L.WgradTask * len(tasks))()
+        for i, t in enumerate(tasks):
+            k = arr[i]
+            k.x_oct, k.gy_oct, k.x_noct, k.gy_noct = t["x_oct"], t["gy_oct"], t["x_noct"], t["gy_noct"]
+            for s, e in t["sub"].items():
+                k.out[s] = e["out"]
+                k.ld[s], k.co_n[s], k.ci0[s], k.co0[s], k.scale[s] = e["ld"], e["co_n"], e["ci0"], e["co0"], e["scale"]
+        dev = self.upload(arr)
+        op = L.Op()
+        op.kind = L.OP_WGRAD
+        d = op.u.wgrad
+        d.dtype, d.ksize, d.stride, d.B, d.H, d.W = self.dt, ksize, stride, B, H, W
+        d.x, d.x_img_stride = x[0].ptr(x[1]), x[0].img_stride
+        d.gy, d.gy_img_stride = gy[0].ptr(gy[1]), gy[0].img_stride
+        d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
+        d.nslices = max(1, _ceil(target_blocks, len(tasks)))
+        ops.append(op)
+
+    def unpack_item(self, src_ptr: int, dst_ptr: int, cout: int, cin: int, taps: int):
+        it = L.UnpackItem()
+        it.src, it.dst, it.cout, it.cin, it.taps, it.accumulate = src_ptr, dst_ptr, cout, cin, taps, 0
+        self.unpack_items.append(it)
+        self.unpack_max = max(self.unpack_max, cout * cin * taps)
+
+    def finalize_unpack(self):
+        if self.unpack_items:
+            arr = (L.UnpackItem * len(self.unpack_items))(*self.unpack_items)
+            self._unpack_dev = self.upload(arr)
+
+    def run_unpack(self):
+        if self._unpack_dev is not None:
+            L.check(self.lib.srx_unpack_wgrad(self._unpack_dev.data_ptr(), len(self.unpack_items),
+                                              self.unpack_max, stream_ptr(self.device)), "srx_unpack_wgrad")
+
+    # --------------------------------------------------------------- run
+    @staticmethod
+    def freeze(ops: list):
+        return (L.Op * len(ops))(*ops) if ops else None
+
+    def run(self, frozen) -> None:
+        if frozen is None:
+            return
+        L.check(self.lib.srx_run_ops(C.addressof(frozen), len(frozen), stream_ptr(self.device)), "srx_run_ops")
+
+    # ----------------------------------------------------- layout helpers
+    def nchw_to_c8(self, src: torch.Tensor, dst: View):
+        buf, o0 = dst
+        B, C_, H, W = src.shape
+        if (B, H, W) != (buf.B, buf.H, buf.W) or _ceil(C_, 8) + o0 > buf.C8:
+            raise ValueError(f"tensor of shape {tuple(src.shape)} does not fit the plan's buffer")
+        src = src.detach().contiguous().float()
+        self._last_src = src        # keep alive until the stream has consumed it
+        L.check(self.lib.srx_nchw_to_c8(self.dt, src.data_ptr(), buf.ptr(o0), buf.img_stride, B, C_, H, W,
+                                        stream_ptr(self.device)), "srx_nchw_to_c8")
+
+    def c8_to_nchw(self, src: View, C_: int) -> torch.Tensor:
+        buf, o0 = src
+        out = torch.empty((buf.B, C_, buf.H, buf.W), dtype=torch.float32, device=self.device)
+        L.check(self.lib.srx_c8_to_nchw(self.dt, buf.ptr(o0), buf.img_stride, out.data_ptr(), buf.B, C_,
+                                        buf.H, buf.W, stream_ptr(self.device)), "srx_c8_to_nchw")
+        return out
+
+
+def conv_seg(weight: torch.Tensor, scale: float = 1.0, scale_ptr: int = 0) -> dict:
+    """Single forward segment for a [cout][cin][k][k] fp32 weight."""
+    return dict(src=weight.data_ptr(), cin_src=weight.shape[1], cout_src=weight.shape[0],
+                c_begin=0, c_count=weight.shape[1], scale=scale, scale_ptr=scale_ptr)
+
+
+def dgrad_seg(weight: torch.Tensor, c_begin: int, src_cin_off: int, scale: float = 1.0,
+              scale_ptr: int = 0) -> dict:
+    """Transposed segment: virtual input channels [c_begin, c_begin+cout_src) are this
+    convolution's output channels; virtual output channel n is its input channel
+    src_cin_off + n."""
+    return dict(src=weight.data_ptr(), cin_src=weight.shape[1], cout_src=weight.shape[0],
+                c_begin=c_begin, c_count=weight.shape[0], src_off=src_cin_off, src_o_off=0,
+                transposed=1, scale=scale, scale_ptr=scale_ptr)
+
+
+# ===========================================================================
+# Generator (esrgan/generator.py:50-72) and its blocks
+# ===========================================================================
+class _GenBase(Plan):
+    """Emitters shared by the whole-generator plan and the stand-alone block plans."""
+
+    def setup_grads(self, P: Dict[str, torch.Tensor], flat_grad: Optional[torch.Tensor] = None):
+        """Flat fp32 gradient buffer in parameter order (+ per-name views), the tap-major
+        staging buffer the kernels accumulate into, and the unpack table between them."""
+        self.param_names = [n for n in P]
+        total = sum(P[n].numel() for n in self.param_names)
+        self.flat_grad = flat_grad if flat_grad is not None else self.f32(total, zero=True)
+        assert self.flat_grad.numel() >= total
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.stage = self.f32(total, zero=True)
+        self._soff: Dict[str, int] = {}
+        off = 0
+        for n in self.param_names:
+            t = P[n]
+            self.grads[n] = self.flat_grad[off:off + t.numel()].view(t.shape)
+            self._soff[n] = off
+            if t.ndim == 4:
+                self.unpack_item(self.sp(n), self.grads[n].data_ptr(), t.shape[0], t.shape[1],
+                                 t.shape[2] * t.shape[3])
+            else:
+                self.unpack_item(self.sp(n), self.grads[n].data_ptr(), 1, t.numel(), 1)
+            off += t.numel()
+
+    def sp(self, name: str) -> int:
+        return self.stage.data_ptr() + 4 * self._soff[name]
+
+    def fwd_layer(self, P, name, perm=0):
+        wt = P[name + ".weight"]
+        return self.packed_layer(wt.shape[0], wt.shape[1], 9, perm, [conv_seg(wt)],
+                                 P[name + ".bias"].data_ptr())
+
+    def dgrad_layer(self, P, name, cout_v):
+        wt = P[name + ".weight"]
+        return self.packed_layer(cout_v, wt.shape[0], 9, 0, [dgrad_seg(wt, 0, 0)], with_bias=False)[0]
+
+    def layer_wgrad(self, ops, P, name, x: View, gy: View, B, Hh, Ww):
+        wt = P[name + ".weight"]
+        tasks = self.wgrad_tasks_for_layer(wt.shape[1], wt.shape[0], 0, 0, self.sp(name + ".weight"))
+        self.wgrad(ops, x, gy, tasks, B, Hh, Ww)
+        self.generic(ops, L.OP_CHANNEL_SUM, a=gy, c_ptr=self.sp(name + ".bias"), B=B, H=Hh, W=Ww,
+                     noct=_ceil(wt.shape[0], 8), f0=1.0)
+
+    # ---- dense block ------------------------------------------------------
+    def emit_rdb_fwd(self, ops, P, pre, cur: Buf, dst: View, B, h, w, nf, gc, q,
+                     rrdb_in: Optional[View]):
+        """ResidualDenseBlock.forward (esrgan/generator.py:17-23); q == 2 also applies the
+        enclosing RRDB's ``out*0.2 + x`` (:37) in the same epilogue."""
+        nf8, gc8 = nf // 8, gc // 8
+        for k in range(1, 5):
+            wp, bp = self.fwd_layer(P, pre + f"conv{k}")
+            self.conv(ops, (cur, 0), (cur, nf8 + (k - 1) * gc8), wp, bp, B, h, w,
+                      nf + (k - 1) * gc, gc, act=LRELU)
+        wp, bp = self.fwd_layer(P, pre + "conv5")
+        if q < 2:
+            self.conv(ops, (cur, 0), dst, wp, bp, B, h, w, nf + 4 * gc, nf,
+                      alpha=RES, res1=(cur, 0), beta1=1.0)
+        else:
+            self.conv(ops, (cur, 0), dst, wp, bp, B, h, w, nf + 4 * gc, nf,
+                      alpha=RES * RES, res1=(cur, 0), beta1=RES, res2=rrdb_in, beta2=1.0)
+
+    def emit_rdb_bwd(self, ops, P, pre, cur: Buf, G: Buf, dst: View, B, h, w, nf, gc, q,
+                     rrdb_g: Optional[View]):
+        """Backward of one dense block.  G = [gy1|gy2|gy3|gy4|g_out]; g_out (the gradient
+        of the block output, or of the RRDB output when q == 2) must already be in place.
+        dst receives the gradient of the block input (+ the RRDB skip gradient rrdb_g when
+        q == 0)."""
+        nf8, gc8 = nf // 8, gc // 8
+        g8 = 4 * gc8
+        s5 = RES * RES if q == 2 else RES
+        W = [P[pre + f"conv{k}.weight"] for k in range(1, 6)]
+        for j in range(4, -1, -1):
+            segs, c0 = [], 0
+            src_off = 0 if j == 0 else nf + (j - 1) * gc
+            for k in range(j + 1, 6):
+                segs.append(dgrad_seg(W[k - 1], c0, src_off, s5 if k == 5 else 1.0))
+                c0 += W[k - 1].shape[0]
+            wp = self.packed_layer(nf if j == 0 else gc, c0, 9, 0, segs, with_bias=False)[0]
+            xin = (G, j * gc8)
+            if j > 0:
+                self.conv(ops, xin, (G, (j - 1) * gc8), wp, 0, B, h, w, c0, gc,
+                          mask=(cur, nf8 + (j - 1) * gc8), mask_slope=LRELU)
+            elif q == 0 and rrdb_g is not None:
+                self.conv(ops, xin, dst, wp, 0, B, h, w, c0, nf, res1=(G, g8), beta1=1.0,
+                          res2=rrdb_g, beta2=1.0)
+            else:
+                self.conv(ops, xin, dst, wp, 0, B, h, w, c0, nf, res1=(G, g8),
+                          beta1=(RES if q == 2 else 1.0))
+        tasks = []
+        for k in range(1, 6):
+            tasks += self.wgrad_tasks_for_layer(nf + (k - 1) * gc, gc if k < 5 else nf, 0, (k - 1) * gc8,
+                                                self.sp(pre + f"conv{k}.weight"), s5 if k == 5 else 1.0)
+        self.wgrad(ops, (cur, 0), (G, 0), self.merge_tasks(tasks), B, h, w)
+        for k in range(1, 6):
+            self.generic(ops, L.OP_CHANNEL_SUM, a=(G, (k - 1) * gc8), c_ptr=self.sp(pre + f"conv{k}.bias"),
+                         B=B, H=h, W=w, noct=(gc8 if k < 5 else nf8), f0=(s5 if k == 5 else 1.0))
+
+    # ---- shared run API ---------------------------------------------------
+    def backward_c8(self) -> None:
+        self.run(self.bwd_ops)
+        self.run_unpack()
+
+
+class GeneratorPlan(_GenBase):
+    """Forward (+ backward) of GeneratorESRGAN for one input shape.
+
+    params: name -> fp32 CUDA tensor with the reference's state_dict names.
+    After backward, ``grads[name]`` are fp32 views of one flat buffer in parameter order.
+    """
+
+    def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
+                 *, in_ch=3, out_ch=3, nf=64, gc=32, num_blocks=23, need_grad=True,
+                 need_input_grad=False, flat_grad: Optional[torch.Tensor] = None):
+        dev = params["conv_first.weight"].device
+        super().__init__(dev, tdtype)
+        if nf % 8 or gc % 8:
+            raise ValueError("num_features and growth channels must be multiples of 8")
+        self.B, self.h, self.w = B, h, w
+        self.in_ch, self.out_ch, self.nf, self.gc, self.nb = in_ch, out_ch, nf, gc, num_blocks
+        self.need_grad, self.need_input_grad = need_grad, need_input_grad
+        self.params = P = params
+        nR = 3 * num_blocks
+        ctot = nf + 4 * gc
+        fwd: list = []
+        self.X0 = self.buf(B, in_ch, h, w)
+        n_ring = nR + 1 if need_grad else min(nR + 1, 4)
+        self.R = [self.buf(B, ctot, h, w) for _ in range(n_ring)]
+        Rb = lambda r: self.R[r % n_ring]
+        self.F = self.buf(B, nf, h, w) if not need_grad else None   # feat copy when R is a ring
+        self.T1 = self.buf(B, nf, h, w)
+        self.U0 = self.buf(B, nf, 2 * h, 2 * w)
+        self.U1 = self.buf(B, nf, 4 * h, 4 * w)
+        self.V = self.buf(B, nf, 4 * h, 4 * w)
+        self.Y = self.buf(B, out_ch, 4 * h, 4 * w)
+
+        wp, bp = self.fwd_layer(P, "conv_first")
+        self.conv(fwd, (self.X0, 0), (Rb(0), 0), wp, bp, B, h, w, in_ch, nf)
+        feat: View = (Rb(0), 0)
+        if not need_grad:
+            self.conv(fwd, (self.X0, 0), (self.F, 0), wp, bp, B, h, w, in_ch, nf)
+            feat = (self.F, 0)
+        for r in range(nR):
+            blk, q = divmod(r, 3)
+            self.emit_rdb_fwd(fwd, P, f"body.{blk}.rdb{q + 1}.", Rb(r), (Rb(r + 1), 0), B, h, w, nf, gc, q,
+                              (Rb(r - 2), 0) if q == 2 else None)
+        wp, bp = self.fwd_layer(P, "conv_body")
+        self.conv(fwd, (Rb(nR), 0), (self.T1, 0), wp, bp, B, h, w, nf, nf, res1=feat, beta1=1.0)
+        wp, bp = self.fwd_layer(P, "upsample.0.conv", perm=1)
+        self.conv(fwd, (self.T1, 0), (self.U0, 0), wp, bp, B, h, w, nf, 4 * nf, act=LRELU, ps=1)
+        wp, bp = self.fwd_layer(P, "upsample.1.conv", perm=1)
+        self.conv(fwd, (self.U0, 0), (self.U1, 0), wp, bp, B, 2 * h, 2 * w, nf, 4 * nf, act=LRELU, ps=1)
+        wp, bp = self.fwd_layer(P, "conv_hr")
+        self.conv(fwd, (self.U1, 0), (self.V, 0), wp, bp, B, 4 * h, 4 * w, nf, nf, act=LRELU)
+        wp, bp = self.fwd_layer(P, "conv_last")
+        self.conv(fwd, (self.V, 0), (self.Y, 0), wp, bp, B, 4 * h, 4 * w, nf, out_ch)
+        self.fwd_ops = self.freeze(fwd)
+        self.bwd_ops = None
+        self.param_names = [n for n in P]
+        if need_grad:
+            self._build_backward(P, Rb, flat_grad)
+        self.finalize_packing()
+        self.finalize_unpack()
+
+    def _build_backward(self, P, Rb, flat_grad):
+        B, h, w, nf, gc, nb = self.B, self.h, self.w, self.nf, self.gc, self.nb
+        in_ch, out_ch = self.in_ch, self.out_ch
+        nR = 3 * nb
+        g8 = 4 * (gc // 8)
+        ctot = nf + 4 * gc
+        H4, W4 = 4 * h, 4 * w
+        bwd: list = []
+        self.setup_grads(P, flat_grad)
+        self.memset(bwd, self.stage)
+        self.GY = self.buf(B, out_ch, H4, W4)           # dL/d(out): filled by the caller / loss kernel
+        self.gV = self.buf(B, nf, H4, W4)
+        self.gU1 = self.buf(B, nf, H4, W4)
+        self.gyu1 = self.buf(B, 4 * nf, 2 * h, 2 * w)
+        self.gU0 = self.buf(B, nf, 2 * h, 2 * w)
+        self.gyu0 = self.buf(B, 4 * nf, h, w)
+        self.gT1 = self.buf(B, nf, h, w)
+        self.G = [self.buf(B, ctot, h, w) for _ in range(nR)]
+        self.gfeat = self.buf(B, nf, h, w)
+        self.gX0 = self.buf(B, in_ch, h, w) if self.need_input_grad else None
+
+        # conv_last: GY -> gV, masked by LeakyReLU'(V)               (esrgan/generator.py:71)
+        self.layer_wgrad(bwd, P, "conv_last", (self.V, 0), (self.GY, 0), B, H4, W4)
+        self.conv(bwd, (self.GY, 0), (self.gV, 0), self.dgrad_layer(P, "conv_last", nf), 0, B, H4, W4,
+                  out_ch, nf, mask=(self.V, 0), mask_slope=LRELU)
+        # conv_hr: gV -> gU1, masked by LeakyReLU'(U1) (activation of upsample.1, :48)
+        self.layer_wgrad(bwd, P, "conv_hr", (self.U1, 0), (self.gV, 0), B, H4, W4)
+        self.conv(bwd, (self.gV, 0), (self.gU1, 0), self.dgrad_layer(P, "conv_hr", nf), 0, B, H4, W4,
+                  nf, nf, mask=(self.U1, 0), mask_slope=LRELU)
+        # upsample.1: inverse shuffle, then conv backward, masked by LeakyReLU'(U0)
+        self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU1, 0), c=(self.gyu1, 0), B=B, C_=nf, H=2 * h, W=2 * w)
+        self.layer_wgrad(bwd, P, "upsample.1.conv", (self.U0, 0), (self.gyu1, 0), B, 2 * h, 2 * w)
+        self.conv(bwd, (self.gyu1, 0), (self.gU0, 0), self.dgrad_layer(P, "upsample.1.conv", nf), 0, B,
+                  2 * h, 2 * w, 4 * nf, nf, mask=(self.U0, 0), mask_slope=LRELU)
+        # upsample.0 (its input T1 = feat + trunk has no activation)
+        self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU0, 0), c=(self.gyu0, 0), B=B, C_=nf, H=h, W=w)
+        self.layer_wgrad(bwd, P, "upsample.0.conv", (self.T1, 0), (self.gyu0, 0), B, h, w)
+        self.conv(bwd, (self.gyu0, 0), (self.gT1, 0), self.dgrad_layer(P, "upsample.0.conv", nf), 0, B, h, w,
+                  4 * nf, nf)
+        # conv_body: gT1 -> gradient of the last RRDB's output
+        self.layer_wgrad(bwd, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w)
+        last_dst = (self.G[nR - 1], g8) if nR else (self.gfeat, 0)
+        self.conv(bwd, (self.gT1, 0), last_dst, self.dgrad_layer(P, "conv_body", nf), 0, B, h, w, nf, nf)
+        for r in range(nR - 1, -1, -1):
+            blk, q = divmod(r, 3)
+            dst = (self.G[r - 1], g8) if r > 0 else (self.gfeat, 0)
+            self.emit_rdb_bwd(bwd, P, f"body.{blk}.rdb{q + 1}.", Rb(r), self.G[r], dst, B, h, w, nf, gc, q,
+                              (self.G[r + 2], g8) if q == 0 else None)
+        # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
+        self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
+                     n=self.gfeat.t.numel())
+        self.layer_wgrad(bwd, P, "conv_first", (self.X0, 0), (self.gfeat, 0), B, h, w)
+        if self.need_input_grad:
+            self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
+                      B, h, w, nf, in_ch)
+        self.bwd_ops = self.freeze(bwd)
+
+    # ------------------------------------------------------------------ API
+    def forward_c8(self, x_nchw: torch.Tensor) -> Buf:
+        """Pack weights, convert the input and run the forward ops; returns Y (C8)."""
+        self.run_packing()
+        self.nchw_to_c8(x_nchw, (self.X0, 0))
+        self.run(self.fwd_ops)
+        return self.Y
+
+    def forward(self, x_nchw: torch.Tensor) -> torch.Tensor:
+        return self.c8_to_nchw((self.forward_c8(x_nchw), 0), self.out_ch)
+
+    def backward(self, gout_nchw: torch.Tensor) -> Optional[torch.Tensor]:
+        self.nchw_to_c8(gout_nchw, (self.GY, 0))
+        self.backward_c8()
+        if self.need_input_grad:
+            return self.c8_to_nchw((self.gX0, 0), self.in_ch)
+        return None
+
+
+class BlockPlan(_GenBase):
+    """Stand-alone ResidualDenseBlock / RRDB / UpsampleBlock (esrgan/generator.py:6-48)."""
+
+    def __init__(self, kind: str, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype, *,
+                 nf=64, gc=32, need_grad=True, need_input_grad=True):
+        dev = next(iter(params.values())).device
+        super().__init__(dev, tdtype)
+        if nf % 8 or gc % 8:
+            raise ValueError("channel counts must be multiples of 8")
+        self.kind, self.B, self.h, self.w, self.nf, self.gc = kind, B, h, w, nf, gc
+        self.need_grad, self.need_input_grad = need_grad, need_input_grad
+        P = params
+        self.param_names = [n for n in P]
+        ctot, g8 = nf + 4 * gc, 4 * (gc // 8)
+        fwd: list = []
+        bwd: list = []
+        if need_grad:
+            self.setup_grads(P)
+            self.memset(bwd, self.stage)
+        if kind in ("rdb", "rrdb"):
+            pres = [""] if kind == "rdb" else ["rdb1.", "rdb2.", "rdb3."]
+            n = len(pres)
+            self.R = [self.buf(B, ctot, h, w) for _ in range(n)]
+            self.OUT = self.buf(B, nf, h, w)
+            self.in_view: View = (self.R[0], 0)
+            self.out_ch = nf
+            for i, pre in enumerate(pres):
+                q = i if kind == "rrdb" else 0
+                dst = (self.R[i + 1], 0) if i + 1 < n else (self.OUT, 0)
+                self.emit_rdb_fwd(fwd, P, pre, self.R[i], dst, B, h, w, nf, gc, q,
+                                  (self.R[0], 0) if q == 2 else None)
+            if need_grad:
+                self.G = [self.buf(B, ctot, h, w) for _ in range(n)]
+                self.gX = self.buf(B, nf, h, w)
+                self.gout_view: View = (self.G[n - 1], g8)
+                for i in range(n - 1, -1, -1):
+                    q = i if kind == "rrdb" else 1      # a lone block: plain "+ g_out" skip
+                    dst = (self.G[i - 1], g8) if i > 0 else (self.gX, 0)
+                    self.emit_rdb_bwd(bwd, P, pres[i], self.R[i], self.G[i], dst, B, h, w, nf, gc, q,
+                                      (self.G[2], g8) if (kind == "rrdb" and q == 0) else None)
+        elif kind == "upsample":
+            self.X = self.buf(B, nf, h, w)
+            self.OUT = self.buf(B, nf, 2 * h, 2 * w)
+            self.in_view = (self.X, 0)
+            self.out_ch = nf
+            wp, bp = self.fwd_layer(P, "conv", perm=1)
+            self.conv(fwd, (self.X, 0), (self.OUT, 0), wp, bp, B, h, w, nf, 4 * nf, act=LRELU, ps=1)
+            if need_grad:
+                self.gOUT = self.buf(B, nf, 2 * h, 2 * w)
+                self.gy = self.buf(B, 4 * nf, h, w)
+                self.gX = self.buf(B, nf, h, w)
+                self.gout_view = (self.gOUT, 0)
+                # LeakyReLU'(out) on the incoming gradient, inverse shuffle, conv backward
+                self.generic(bwd, L.OP_ACT_BWD, a=(self.gOUT, 0), mask=(self.OUT, 0), c=(self.gOUT, 0),
+                             f0=LRELU, n=self.gOUT.t.numel())
+                self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gOUT, 0), c=(self.gy, 0), B=B, C_=nf, H=h, W=w)
+                self.layer_wgrad(bwd, P, "conv", (self.X, 0), (self.gy, 0), B, h, w)
+                self.conv(bwd, (self.gy, 0), (self.gX, 0), self.dgrad_layer(P, "conv", nf), 0, B, h, w, 4 * nf, nf)
+        else:
+            raise ValueError(kind)
+        self.fwd_ops = self.freeze(fwd)
+        self.bwd_ops = self.freeze(bwd) if need_grad else None
+        self.finalize_packing()
+        self.finalize_unpack()
+
+    def forward(self, x_nchw: torch.Tensor) -> torch.Tensor:
+        self.run_packing()
+        self.nchw_to_c8(x_nchw, self.in_view)
+        self.run(self.fwd_ops)
+        return self.c8_to_nchw((self.OUT, 0), self.out_ch)
+
+    def backward(self, gout_nchw: torch.Tensor) -> Optional[torch.Tensor]:
+        self.nchw_to_c8(gout_nchw, self.gout_view)
+        self.backward_c8()
+        return self.c8_to_nchw((self.gX, 0), self.nf)

@@ -1,0 +1,78 @@
+"""GPU parity of the HIP convolution (C ABI srx_conv2d) against the CPU oracle."""
+import pytest
+import torch
+
+from helpers import O, TOL, rel_err, run_single_conv
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, cin, cout, H, W, stride
+    (2, 64, 32, 12, 20, 1),
+    (1, 96, 32, 33, 40, 1),
+    (2, 192, 64, 16, 64, 1),
+    (1, 3, 64, 17, 9, 1),
+    (1, 64, 3, 40, 24, 1),
+    (2, 64, 64, 32, 32, 2),
+    (1, 128, 128, 16, 16, 2),
+    (1, 256, 256, 8, 8, 1),
+    (1, 3, 64, 64, 64, 2),
+    (1, 16, 48, 8, 8, 1),
+    (1, 64, 32, 130, 70, 1),
+]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_bias_lrelu(case, tdtype):
+    B, cin, cout, H, W, stride = case
+    x = O.hash_input(f"x{case}", (B, cin, H, W))
+    w = O.hash_uniform(f"w{case}", (cout, cin, 3, 3), (3.0 / (9 * cin)) ** 0.5)
+    b = O.hash_uniform(f"b{case}", (cout,), 0.1)
+    ref = O.lrelu(O.conv3x3(x, w, b, stride))
+    out = run_single_conv(x, w, b, stride=stride, tdtype=tdtype, act=0.2)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[tdtype]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+def test_conv_residual_mask(tdtype):
+    x = O.hash_input("xr", (2, 192, 10, 36))
+    w = O.hash_uniform("wr", (64, 192, 3, 3), (3.0 / (9 * 192)) ** 0.5)
+    b = O.hash_uniform("br", (64,), 0.1)
+    res = O.hash_input("res", (2, 64, 10, 36))
+    mask = O.hash_input("mask", (2, 64, 10, 36))
+    y = O.conv3x3(x, w, b)
+    ref = 0.2 * (y * torch.where(mask > 0, 1.0, 0.3)) + 0.5 * res
+    out = run_single_conv(x, w, b, tdtype=tdtype, alpha=0.2, res=res, beta=0.5, mask=mask, mask_slope=0.3)
+    assert rel_err(out, ref) < TOL[tdtype]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+def test_conv_pixel_shuffle(tdtype):
+    x = O.hash_input("xp", (2, 64, 9, 33))
+    w = O.hash_uniform("wp", (256, 64, 3, 3), (3.0 / (9 * 64)) ** 0.5)
+    b = O.hash_uniform("bp", (256,), 0.1)
+    ref = O.lrelu(O.pixel_shuffle2(O.conv3x3(x, w, b)))
+    out = run_single_conv(x, w, b, tdtype=tdtype, act=0.2, ps=1)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[tdtype]
+
+
+def test_pixel_shuffle_indexing_bit_exact():
+    """Integer-valued data through an identity centre-tap conv: the PixelShuffle scatter
+    must reproduce nn.PixelShuffle(2) exactly (reference esrgan/generator.py:44)."""
+    import numpy as np
+    from helpers import golden
+    man, arr = golden()
+    cin = cout = 32
+    x = (torch.arange(1 * cin * 5 * 7) % 251).float().reshape(1, cin, 5, 7)
+    w = torch.zeros(cout, cin, 3, 3)
+    for c in range(cout):
+        w[c, c, 1, 1] = 1.0
+    for tdtype in (torch.float32, torch.bfloat16):
+        out = run_single_conv(x, w, None, tdtype=tdtype, ps=1)
+        assert torch.equal(out, O.pixel_shuffle2(x))
+    # and the oracle's index formula equals the reference's nn.PixelShuffle output (golden)
+    xg = torch.arange(2 * 8 * 3 * 5, dtype=torch.float32).reshape(2, 8, 3, 5)
+    assert np.array_equal(O.pixel_shuffle2(xg).numpy().astype(np.int32), arr["pixel_shuffle_out"])

@@ -1,0 +1,96 @@
+"""GPU parity of the generator modules (drop-in nn.Module API) against the golden
+fixtures produced by the real reference and against the CPU oracle."""
+import pytest
+import torch
+
+from helpers import O, TOL, fill_module_, golden, pkg, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads_close(module, gold_grads, tol):
+    bad = []
+    for n, p in module.named_parameters():
+        g = p.grad.detach().double().cpu().flatten()
+        ref = gold_grads[n]
+        nr = ref["norm"]
+        err = abs(float(g.norm()) - nr) / max(nr, 1e-12)
+        head = torch.tensor(ref["head"], dtype=torch.float64)
+        herr = float((g[:8] - head).abs().max()) / max(nr / max(g.numel(), 1) ** 0.5, 1e-12)
+        if err > tol or herr > 40 * tol:
+            bad.append((n, err, herr))
+    return bad
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["rdb", "rrdb", "upsample"])
+def test_blocks_match_reference(name, tdtype):
+    G = pkg("esrgan.generator")
+    man, arr = golden()
+    case = man["cases"][name]
+    mod = {"rdb": lambda: G.ResidualDenseBlock(64, 32), "rrdb": lambda: G.RRDB(64),
+           "upsample": lambda: G.UpsampleBlock(64)}[name]()
+    fill_module_(mod, salt=1)
+    mod = mod.cuda()
+    mod.compute_dtype = tdtype
+    shape = {"rdb": (2, 64, 12, 20), "rrdb": (2, 64, 12, 20), "upsample": (2, 64, 6, 10)}[name]
+    x = O.hash_input(name + ".x", shape).cuda().requires_grad_(True)
+    y = mod(x)
+    ref_y = torch.from_numpy(arr[name + "_y"])
+    assert rel_err(y, ref_y) < TOL[tdtype]
+    gy = O.hash_input(name + ".gy", ref_y.shape).cuda()
+    (y * gy).sum().backward()
+    assert rel_err(x.grad, torch.from_numpy(arr[name + "_gx"])) < TOL[tdtype] * 2
+    bad = _grads_close(mod, case["grads"], TOL[tdtype])
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+def test_generator_1block_matches_reference(tdtype):
+    G = pkg("esrgan.generator")
+    man, arr = golden()
+    case = man["cases"]["g1"]
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=2).cuda()
+    g.compute_dtype = tdtype
+    lr = O.hash_input("g1.lr", (2, 3, 16, 24)).cuda().requires_grad_(True)
+    hr = O.hash_input("g1.hr", (2, 3, 64, 96)).cuda()
+    out = g(lr)
+    assert rel_err(out, torch.from_numpy(arr["g1_out"])) < TOL[tdtype]
+    loss = torch.nn.L1Loss()(out, hr)
+    assert abs(float(loss) - case["loss_value"]) / case["loss_value"] < TOL[tdtype]
+    loss.backward()
+    assert rel_l2(lr.grad, torch.from_numpy(arr["g1_glr"])) < TOL[tdtype] * 2
+    bad = _grads_close(g, case["grads"], TOL[tdtype] * 2)
+    assert not bad, bad[:5]
+
+
+def test_generator_23_config1_fp32_matches_reference():
+    """BASELINE config 1: 23 RRDB, batch 4 of 32x32 LR, fp32 — against the reference's output."""
+    G = pkg("esrgan.generator")
+    man, arr = golden()
+    case = man["cases"]["g23"]
+    g = fill_module_(G.GeneratorESRGAN(), salt=3).cuda()
+    lr = O.hash_input("g23.lr", (4, 3, 32, 32)).cuda()
+    hr = O.hash_input("g23.hr", (4, 3, 128, 128)).cuda()
+    out = g(lr)
+    samp = out.detach().flatten()[::7].cpu()
+    assert rel_err(samp, torch.from_numpy(arr["g23_out_s7"])) < 1e-3
+    assert abs(float(out.double().sum()) - case["out_sum"]) / case["out_abs_sum"] < 1e-4
+    loss = torch.nn.L1Loss()(out, hr)
+    assert abs(float(loss) - case["loss_value"]) / case["loss_value"] < 1e-3
+    loss.backward()
+    bad = _grads_close(g, case["grads"], 2e-3)
+    assert not bad, bad[:5]
+
+
+def test_generator_23_bf16_forward_close():
+    G = pkg("esrgan.generator")
+    man, arr = golden()
+    g = fill_module_(G.GeneratorESRGAN(), salt=3).cuda()
+    g.compute_dtype = torch.bfloat16
+    lr = O.hash_input("g23.lr", (4, 3, 32, 32)).cuda()
+    with torch.no_grad():
+        out = g(lr)
+    samp = out.flatten()[::7].cpu()
+    ref = torch.from_numpy(arr["g23_out_s7"])
+    assert rel_l2(samp, ref) < 2e-2
