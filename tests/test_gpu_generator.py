@@ -57,8 +57,14 @@ def test_generator_1block_matches_reference(tdtype):
     out = g(lr)
     assert rel_err(out, torch.from_numpy(arr["g1_out"])) < TOL[tdtype]
     loss = torch.nn.L1Loss()(out, hr)
-    assert abs(float(loss) - case["loss_value"]) / case["loss_value"] < TOL[tdtype]
-    loss.backward()
+    assert abs(float(loss.detach()) - case["loss_value"]) / case["loss_value"] < TOL[tdtype]
+    if tdtype == torch.float32:
+        loss.backward()
+    else:
+        # sign(out-hr) is discontinuous: bf16 rounding flips it where out ~ hr, which is a
+        # property of the L1 loss, not of the kernels.  Feed the reference's own dL/d(out).
+        ref_out = torch.from_numpy(arr["g1_out"]).cuda()
+        out.backward(torch.sign(ref_out - hr) / ref_out.numel())
     assert rel_l2(lr.grad, torch.from_numpy(arr["g1_glr"])) < TOL[tdtype] * 2
     bad = _grads_close(g, case["grads"], TOL[tdtype] * 2)
     assert not bad, bad[:5]
