@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""ESRGAN hot-path benchmark (see BASELINE.json: LR Mpixels/s of the 4x train step).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N == 1 workload: BASELINE config 2 — 23-RRDB generator warm-up (L1 pixel loss),
+forward + backward + Adam, batch 16 of 64x64 LR patches, bf16 MFMA, synthetic
+data, default-initialised weights.  For N > 1 the driver launches one rank per GPU
+(torch.distributed.run); each rank takes its own batch of 16 (weak scaling) and the
+gradients are averaged over RCCL before the optimizer step.
+
+Prints ONE JSON line on rank 0 with the throughput, a roofline object for the
+dominant kernel (measured live with events around every launch of one extra,
+untimed step) and, at N == 1, the CPU baseline (the oracle's plain-PyTorch
+restatement of the same step on the host cores, bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_LR_PX_FWD_BWD = 107_561_088      # 3 x 17,926,848 MAC x 2 (conv MACs only)
+PEAK_BF16_TFLOPS = 2500.0                  # MI355X dense bf16 MFMA peak
+
+
+def profile_ops(plan, ctypes_mod):
+    """Events around every launch of one forward+backward; returns {kernel: [time_ms, flops, n]}."""
+    stats = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    lib = plan.lib
+    seqs = [(plan.fwd_ops, plan.fwd_meta), (plan.bwd_ops, plan.bwd_meta)]
+    evs = []
+    for ops, meta in seqs:
+        for i in range(len(ops)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.srx_run_ops(ctypes_mod.addressof(ops[i]), 1, stream)
+            e1.record()
+            assert rc == 0
+            evs.append((meta[i], e0, e1))
+    torch.cuda.synchronize()
+    for (name, flops), e0, e1 in evs:
+        s = stats.setdefault(name, [0.0, 0.0, 0])
+        s[0] += e0.elapsed_time(e1)
+        s[1] += flops
+        s[2] += 1
+    return stats
+
+
+def cpu_baseline(iters=3):
+    """Oracle (plain PyTorch fp32 restatement) of the same step on the host cores:
+    23-RRDB generator fwd + L1 + bwd on B=4 of 32x32 LR (BASELINE config 1 shape)."""
+    from oracle import esrgan_oracle as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    torch.set_num_threads(cores)
+    sd = O.make_state_dict(O.generator_state_dict_spec(23), salt=3)
+    for v in sd.values():
+        v.requires_grad_(True)
+    lr = O.hash_input("bench.lr", (4, 3, 32, 32))
+    hr = O.hash_input("bench.hr", (4, 3, 128, 128))
+
+    def one():
+        out = O.generator_forward(lr, sd)
+        loss = O.l1_loss(out, hr)
+        grads = torch.autograd.grad(loss, list(sd.values()))
+        return grads
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": 4 * 32 * 32 / dt / 1e6, "unit": "LR Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "oracle generator fwd+L1+bwd, fp32, B=4 of 32x32 LR (config-1 shape), "
+                      f"{iters} timed iters after 1 warm-up, {dt:.3f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--patch", type=int, default=64)
+    ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ctypes
+    G = importlib.import_module("super-resolution_amd.esrgan.generator")
+    T = importlib.import_module("super-resolution_amd.train")
+    D = importlib.import_module("super-resolution_amd.parallel")
+
+    torch.manual_seed(0)
+    gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
+    B, h = args.batch, args.patch
+    sync = D.FlatGradAllReduce(world) if world > 1 else None
+    trainer = T.GeneratorWarmupTrainer(gen, (B, 3, h, h), torch.bfloat16, grad_sync=sync)
+    gcpu = torch.Generator().manual_seed(1234 + rank)
+    lr = (torch.rand((B, 3, h, h), generator=gcpu) * 2 - 1).to(dev)
+    hr = (torch.rand((B, 3, 4 * h, 4 * h), generator=gcpu) * 2 - 1).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(lr, hr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(lr, hr)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = trainer.mean_loss()
+
+    px_per_step = world * B * h * h
+    value = px_per_step * args.steps / dt / 1e6
+    tflops = value * 1e6 * FLOP_PER_LR_PX_FWD_BWD / 1e12     # valid for the 23-block generator
+    out = {
+        "metric": "LR Mpixels/sec ESRGAN 4x train step (fwd+bwd)", "value": round(value, 4),
+        "unit": "LR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"config 2: 23-RRDB generator warm-up (L1), fwd+bwd+Adam, batch {B}/GPU "
+                               f"of {h}x{h} LR patches, bf16" if args.blocks == 23 else
+                               f"{args.blocks}-RRDB generator warm-up, batch {B}, {h}x{h}",
+                   "global_batch": world * B, "lr_patch": h, "parallelism": f"dp{world}",
+                   "final_l1_loss": round(loss, 5)},
+        "algorithmic_tflops": round(tflops, 2) if args.blocks == 23 else None,
+        "pct_bf16_mfma_peak": round(100 * tflops / (PEAK_BF16_TFLOPS * world), 2) if args.blocks == 23 else None,
+    }
+
+    if rank == 0 and not args.no_profile:
+        stats = profile_ops(trainer.plan, ctypes)
+        tot = sum(v[0] for v in stats.values())
+        name, (ms, flops, n) = max(stats.items(), key=lambda kv: kv[1][0])
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches": n, "avg_us": round(ms * 1e3 / n, 2),
+                           "share_of_step_kernel_time": round(ms / tot, 3)}
+        out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0]
+                                      for k, v in sorted(stats.items(), key=lambda kv: -kv[1][0])[:8]}
+    if dist is not None:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

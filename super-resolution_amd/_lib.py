@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch's ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the
+# one already mapped when libsrx.so is opened, so that our kernels and torch's allocator/streams
+# share a single runtime instance; importing torch first guarantees that order.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrx.so")
 

@@ -70,6 +70,32 @@ class Buf:
 View = Tuple[Buf, int]   # (buffer, first octet plane)
 
 
+class OpList(list):
+    """List of L.Op plus, per op, (kernel name, algorithmic FLOPs) for the benchmark."""
+
+    def __init__(self):
+        super().__init__()
+        self.meta: List[Tuple[str, float]] = []
+
+
+def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: int) -> str:
+    """Mirror of the instantiation choice in csrc/conv.hip (dispatch<T>)."""
+    t = "bf16" if dt == L.BF16 else "float"
+    nb = 2 if (_ceil(cout, 32) % 2 == 0) else 1
+    if ksize == 1:
+        cfg = (1, nb, 1, 5, 1)
+    elif stride == 1:
+        if OW >= 24:
+            cfg = (1, 1, 4, 5, 3) if (OH * OW >= 128 * 128 and nb == 1) else (1, nb, 2, 5, 3)
+        elif OW >= 12:
+            cfg = (1, nb, 1, 4, 3)
+        else:
+            cfg = (1, nb, 1, 3, 3)
+    else:
+        cfg = (2, nb, 1, 5 if OW >= 24 else (4 if OW >= 12 else 3), 3)
+    return "conv_kernel<%s,%d,%d,%d,%d,%d>" % ((t,) + cfg)
+
+
 class Plan:
     """Recorder of ops + owner of buffers.  Subclasses build the op lists."""
 
@@ -183,6 +209,11 @@ class Plan:
         if res2 is not None:
             d.res2, d.res2_img_stride, d.beta2 = res2[0].ptr(res2[1]), res2[0].img_stride, beta2
         ops.append(op)
+        if isinstance(ops, OpList):
+            pad = ksize // 2
+            OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+            ops.meta.append((conv_kernel_name(self.dt, ksize, stride, OH, OW, cout),
+                             2.0 * B * OH * OW * ksize * ksize * cin * cout))
 
     def generic(self, ops: list, kind: int, *, a: Optional[View] = None, b: Optional[View] = None,
                 c: Optional[View] = None, c_ptr: int = 0, mask: Optional[View] = None,
@@ -203,6 +234,8 @@ class Plan:
             g.mask, g.mask_img_stride = mask[0].ptr(mask[1]), mask[0].img_stride
         g.f0, g.f1, g.n = f0, f1, n
         ops.append(op)
+        if isinstance(ops, OpList):
+            ops.meta.append(("op%d" % kind, 0.0))
 
     def memset(self, ops: list, t: torch.Tensor):
         self.generic(ops, L.OP_MEMSET, c_ptr=t.data_ptr(), n=t.numel() * t.element_size())
@@ -262,6 +295,16 @@ class Plan:
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
         d.nslices = max(1, _ceil(target_blocks, len(tasks)))
         ops.append(op)
+        if isinstance(ops, OpList):
+            pad = ksize // 2
+            OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+            pairs = sum(min(32, e["ld"] - e["ci0"]) * min(32, e["co_n"] - e["co0"])
+                        for t in tasks for e in t["sub"].values())
+            ltw = 5 if OW >= 24 else (4 if OW >= 12 else 3)
+            tp = 32 if (self.dt == L.F32 and stride == 2) else 128
+            name = "wgrad_kernel<%s,%d,%d,%d,%d>" % ("bf16" if self.dt == L.BF16 else "float",
+                                                     stride, 5 if ksize == 1 else ltw, ksize, tp)
+            ops.meta.append((name, 2.0 * B * OH * OW * ksize * ksize * pairs))
 
     def unpack_item(self, src_ptr: int, dst_ptr: int, cout: int, cin: int, taps: int):
         it = L.UnpackItem()
@@ -451,7 +494,7 @@ class GeneratorPlan(_GenBase):
         self.params = P = params
         nR = 3 * num_blocks
         ctot = nf + 4 * gc
-        fwd: list = []
+        fwd = OpList()
         self.X0 = self.buf(B, in_ch, h, w)
         n_ring = nR + 1 if need_grad else min(nR + 1, 4)
         self.R = [self.buf(B, ctot, h, w) for _ in range(n_ring)]
@@ -484,6 +527,7 @@ class GeneratorPlan(_GenBase):
         wp, bp = self.fwd_layer(P, "conv_last")
         self.conv(fwd, (self.V, 0), (self.Y, 0), wp, bp, B, 4 * h, 4 * w, nf, out_ch)
         self.fwd_ops = self.freeze(fwd)
+        self.fwd_meta = fwd.meta
         self.bwd_ops = None
         self.param_names = [n for n in P]
         if need_grad:
@@ -498,7 +542,7 @@ class GeneratorPlan(_GenBase):
         g8 = 4 * (gc // 8)
         ctot = nf + 4 * gc
         H4, W4 = 4 * h, 4 * w
-        bwd: list = []
+        bwd = OpList()
         self.setup_grads(P, flat_grad)
         self.memset(bwd, self.stage)
         self.GY = self.buf(B, out_ch, H4, W4)           # dL/d(out): filled by the caller / loss kernel
@@ -547,6 +591,7 @@ class GeneratorPlan(_GenBase):
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
         self.bwd_ops = self.freeze(bwd)
+        self.bwd_meta = bwd.meta
 
     # ------------------------------------------------------------------ API
     def forward_c8(self, x_nchw: torch.Tensor) -> Buf:
