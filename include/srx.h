@@ -122,6 +122,8 @@ int srx_conv2d(const srx_conv_desc* d, void* stream);
  * sub-blocks (cin half a, cout half b), each accumulated into a [taps][Cout][Cin]
  * fp32 "tap-major" gradient tensor with atomic adds. */
 typedef struct srx_wgrad_task {
+  const void* x;         /* image-0 base of this task's input view  (NULL: desc.x)  */
+  const void* gy;        /* image-0 base of its gradient view       (NULL: desc.gy) */
   int32_t x_oct;         /* first input octet plane (relative to x view)            */
   int32_t gy_oct;        /* first output-gradient octet plane (relative to gy view) */
   int32_t x_noct;        /* valid x octets from x_oct (<= 8)                        */
@@ -132,12 +134,16 @@ typedef struct srx_wgrad_task {
   int32_t ci0[4];        /* cin index of sub-block row 0 in that tensor             */
   int32_t co0[4];        /* cout index of sub-block col 0 in that tensor            */
   float scale[4];
+  float* bias_out[2];    /* per cout half b: fp32 bias-gradient tensor or NULL      */
+  int32_t bias_co0[2];   /* cout index of that half's first column                  */
+  int32_t bias_n[2];     /* Cout of that tensor                                     */
+  float bias_scale[2];
 } srx_wgrad_task;
 
 typedef struct srx_wgrad_desc {
   int32_t dtype, ksize, stride;
   int32_t B, H, W;       /* INPUT (x) spatial size; gy is H/stride x W/stride       */
-  const void* x;  int64_t x_img_stride;
+  const void* x;  int64_t x_img_stride;   /* x/gy may be NULL if every task has its own */
   const void* gy; int64_t gy_img_stride;
   const srx_wgrad_task* tasks;   /* DEVICE array                                   */
   int32_t ntasks;

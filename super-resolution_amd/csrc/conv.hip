@@ -87,8 +87,17 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   const T* wb = reinterpret_cast<const T*>(p.w);
 
   // ---- per-thread staging plan (independent of the chunk) ----
-  int xoff[NXS];
-  unsigned xok = 0, xh1 = 0;                // validity / "second octet" bitmasks
+  // Activation pieces come through a buffer descriptor over this image's view: an
+  // out-of-image pixel (zero padding) gets an offset beyond the descriptor's range and the
+  // hardware returns zeros, as it does for the second octet of the last chunk when the
+  // channel count is not a multiple of 16.  No load is ever conditional, so the loads of
+  // chunk c+1 stay in flight behind the MFMAs of chunk c.
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned plane_bytes = (unsigned)(plane_in * sizeof(T));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(xb), 0, (int)((unsigned)p.cin8 * plane_bytes), 0x00020000);
+  unsigned xoff[NXS];
+  unsigned xok = 0;
 #pragma unroll
   for (int i = 0; i < NXS; ++i) {
     int piece = tid + i * 256;
@@ -98,31 +107,32 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     int r = pix / IW, c = pix % IW;
     int gy = iy0 + r, gx = ix0 + c;
     bool ok = piece < XP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    xoff[i] = ok ? (int)(h * plane_in + ((long)gy * p.W + gx) * 8 + q * EPP) : 0;
+    xoff[i] = (unsigned)h * plane_bytes + (unsigned)(((gy * p.W + gx) * 8 + q * EPP) * (int)sizeof(T));
     if (ok) xok |= 1u << i;
-    if (h) xh1 |= 1u << i;
+  }
+  int woff[NWS];
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    int piece = tid + i * 256;
+    if (piece >= WP) piece = WP - 1;
+    int nb = piece / (TAPS * 64 * PPO);
+    int rem = piece % (TAPS * 64 * PPO);
+    woff[i] = (nb0 + nb) * p.nchunk * (TAPS * 512) + rem * EPP;
   }
 
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   uint4 xr[NXS], wr[NWS];
   auto load_regs = [&](int chunk) {
-    const T* xc = xb + (long)chunk * 2 * plane_in;
-    const bool has_h1 = chunk * 2 + 1 < p.cin8;
+    const unsigned coff = (unsigned)chunk * 2u * plane_bytes;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
-      bool ok = (xok >> i) & 1;
-      if (((xh1 >> i) & 1) && !has_h1) ok = false;
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(xc + xoff[i]) : make_uint4(0, 0, 0, 0);
+      unsigned vo = ((xok >> i) & 1) ? xoff[i] + coff : OOB;
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0);
+      xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+    const T* wc = wb + (long)chunk * (TAPS * 512);
 #pragma unroll
-    for (int i = 0; i < NWS; ++i) {
-      int piece = tid + i * 256;
-      if (piece < WP) {
-        int nb = piece / (TAPS * 64 * PPO);
-        int rem = piece % (TAPS * 64 * PPO);
-        const T* src = wb + ((long)(nb0 + nb) * p.nchunk + chunk) * (TAPS * 512) + rem * EPP;
-        wr[i] = *reinterpret_cast<const uint4*>(src);
-      }
-    }
+    for (int i = 0; i < NWS; ++i) wr[i] = *reinterpret_cast<const uint4*>(wc + woff[i]);
   };
   auto store_lds = [&](int stage) {
     uint4* sx = smem + stage * STAGE;

@@ -1,4 +1,4 @@
-// Weight gradient of a 3x3 / 1x1 convolution on 32x32 MFMA tiles (gfx950).
+// Weight (and bias) gradient of a 3x3 / 1x1 convolution on 32x32 MFMA tiles (gfx950).
 //
 // GEMM view per tap:  dW[tap][cout][cin] = sum_pixels GY[cout][p] * X[cin][p + tap],
 // i.e. the contraction index is the PIXEL.  Activations are pixel-major (C8
@@ -6,12 +6,18 @@
 // ds_read_b64_tr_b16 (bf16) or gathered with ds_read_b32 (fp32).
 //
 // One workgroup owns a 64(cin) x 64(cout) block of one or several layers (a
-// task); its 4 waves each hold the 9-tap accumulators of one 32x32 sub-block
-// (144 registers) across all the pixel tiles of the workgroup's slice, then add
-// them with fp32 atomics into tap-major gradient tensors ([tap][cout][cin]: the
-// 32 lanes of a half-wave are 32 consecutive cin, i.e. 128 contiguous bytes).
-// A dense block's five convolutions are one launch: the task table encodes
-// which (cin block, cout block) pairs exist and where each lands.
+// task) and a slice of the pixel tiles; its 4 waves each hold the 9-tap
+// accumulators of one 32x32 sub-block (144 registers) across all tiles of the
+// slice, then add them with fp32 atomics into tap-major gradient tensors
+// ([tap][cout][cin]: the 32 lanes of a half-wave are 32 consecutive cin, i.e.
+// 128 contiguous bytes per atomic instruction half).  The bias gradient is one
+// more MFMA per k-step against an all-ones operand.
+//
+// Pipeline: register-staged double buffering (tile t+1's global loads are in
+// flight behind tile t's MFMAs; one barrier per tile).  For stride 1 the X
+// fragments of an input row are read once and used by the three taps dy that map
+// it to an output row.  Octet planes in LDS are padded to 4 (mod 8) slots so the
+// transposed reads of a 32-lane half fall on 32 distinct 8-byte banks.
 #include "srx_common.h"
 
 namespace {
@@ -39,7 +45,6 @@ __device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // 8 consecutive-pixel bf16 values of one channel: two transposed 4x16 block reads.
-// addr0/addr1: this lane's byte addresses (LDS) for pixel quads 0 and 1.
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_base, int addr0, int addr1) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + addr0));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + addr1));
@@ -47,6 +52,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_base, int addr0, int a
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
+
+constexpr int pad4mod8(int n) { return n + ((4 - n % 8) + 8) % 8; }
 
 template <typename T, int STRIDE, int LTW, int KS, int TPIX>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -58,33 +65,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int IH = (TH - 1) * STRIDE + KS;
   constexpr int IW = (TW - 1) * STRIDE + KS;
   constexpr int NPX = IH * IW;
+  constexpr int PSX = pad4mod8(NPX);        // LDS octet-plane stride (slots) of the X tile
+  constexpr int PSG = pad4mod8(TPIX);       // ... of the GY tile
   constexpr int PPO = Oct<T>::PPO;
   constexpr int EPP = 16 / sizeof(T);
-  constexpr int XP = 8 * NPX * PPO;
+  constexpr int XP = 8 * NPX * PPO;         // pieces loaded per tile
   constexpr int GP = 8 * TPIX * PPO;
   constexpr int NXS = (XP + 255) / 256;
   constexpr int NGS = (GP + 255) / 256;
   constexpr int KSTEPS = TPIX / 16;
   constexpr int OB = sizeof(T) * 8;         // bytes per octet slot
+  constexpr int STAGE = (8 * PSX + 8 * PSG) * PPO;   // 16-byte pieces per stage
+  constexpr bool ROWREUSE = (STRIDE == 1 && LTW >= 4 && KS == 3);
 
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  uint4* sx = smem;
-  uint4* sg = smem + XP;
-  const char* sxb = reinterpret_cast<const char*>(sx);
-  const char* sgb = reinterpret_cast<const char*>(sg);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int task_id = blockIdx.x / p.nslices, slice = blockIdx.x % p.nslices;
   const srx_wgrad_task* __restrict__ tkp = p.tasks + task_id;
   const int sa = wave & 1, sb = wave >> 1;      // cin half, cout half
   float* const outp = tkp->out[sa + 2 * sb];
+  float* const biasp = sa == 0 ? tkp->bias_out[sb] : nullptr;
   const int x_noct = tkp->x_noct, gy_noct = tkp->gy_noct;
-  const bool active = outp != nullptr;          // wave-uniform
+  const bool active = outp != nullptr || biasp != nullptr;     // wave-uniform
+  const bool do_bias = biasp != nullptr;
 
   const long plane_x = (long)p.H * p.W * 8;
   const long plane_g = (long)p.OH * p.OW * 8;
-  const T* xbase = reinterpret_cast<const T*>(p.x) + (long)tkp->x_oct * plane_x;
-  const T* gbase = reinterpret_cast<const T*>(p.gy) + (long)tkp->gy_oct * plane_g;
+  const T* xbase = reinterpret_cast<const T*>(tkp->x ? tkp->x : p.x) + (long)tkp->x_oct * plane_x;
+  const T* gbase = reinterpret_cast<const T*>(tkp->gy ? tkp->gy : p.gy) + (long)tkp->gy_oct * plane_g;
 
   // ---- per-lane LDS read addresses (bytes), tap (0,0), k-step 0 ----
   int ga[2], xa[2];      // bf16: two transposed reads; fp32: [0] only (element address)
@@ -95,118 +104,202 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int kp = 8 * h + 4 * t + q;        // pixel inside the 16-pixel k-step
-      ga[t] = ((4 * sb + osub) * TPIX + kp) * OB + 8 * (pq & 1);
+      ga[t] = ((4 * sb + osub) * PSG + kp) * OB + 8 * (pq & 1);
       const int py = kp >> LTW, px = kp & (TW - 1);   // for k-step 0; later steps add a constant
-      xa[t] = ((4 * sa + osub) * NPX + py * STRIDE * IW + px * STRIDE) * OB + 8 * (pq & 1);
+      xa[t] = ((4 * sa + osub) * PSX + py * STRIDE * IW + px * STRIDE) * OB + 8 * (pq & 1);
     }
   } else {
     const int r = lane & 31, h = lane >> 5;
-    ga[0] = ((4 * sb + (r >> 3)) * TPIX + h) * OB + (r & 7) * 4;
-    xa[0] = ((4 * sa + (r >> 3)) * NPX + h * STRIDE) * OB + (r & 7) * 4;   // TW >= 2
+    ga[0] = ((4 * sb + (r >> 3)) * PSG + h) * OB + (r & 7) * 4;
+    xa[0] = ((4 * sa + (r >> 3)) * PSX + h * STRIDE) * OB + (r & 7) * 4;   // TW >= 2
     ga[1] = xa[1] = 0;
   }
 
+  auto load_g = [&](const char* sgb, int ks) -> frag_t {
+    const int gofs = ks * 16 * OB;
+    frag_t gf;
+    if constexpr (sizeof(T) == 2) {
+      gf = tr_frag(sgb, ga[0] + gofs, ga[1] + gofs);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) gf[s] = *reinterpret_cast<const float*>(sgb + ga[0] + gofs + 2 * s * OB);
+    }
+    return gf;
+  };
+  // X fragment whose 16 pixels start at tile-input position (row, col) [slots]
+  auto load_x = [&](const char* sxb, int row, int col) -> frag_t {
+    const int xofs = (row * IW + col) * OB;
+    frag_t xf;
+    if constexpr (sizeof(T) == 2) {
+      xf = tr_frag(sxb, xa[0] + xofs, xa[1] + xofs);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        int po;
+        if constexpr (LTW >= 4) po = 2 * s * STRIDE * OB;
+        else po = (((2 * s) >> 3) * STRIDE * IW + ((2 * s) & 7) * STRIDE) * OB;
+        xf[s] = *reinterpret_cast<const float*>(sxb + xa[0] + xofs + po);
+      }
+    }
+    return xf;
+  };
+
   f32x16 acc[TAPS];
+  f32x16 accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  frag_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
 
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int ntiles = p.B * tiles_per_img;
 
-  for (int tile = slice; tile < ntiles; tile += p.nslices) {
+  // ---- staging: unconditional buffer loads (out-of-image pixels and octets beyond the
+  // task's valid range get an out-of-range offset and read as zero) ----
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned xbytes = (unsigned)x_noct * (unsigned)(plane_x * sizeof(T));
+  const unsigned gbytes = (unsigned)gy_noct * (unsigned)(plane_g * sizeof(T));
+  // per-thread piece -> (octet, tile pixel) decomposition is tile independent
+  // packed per-piece info: octet | row << 8 | col << 16 | q << 24 ; LDS piece index (or -1)
+  int xinfo[NXS], xl_[NXS];
+#pragma unroll
+  for (int i = 0; i < NXS; ++i) {
+    int piece = tid + i * 256;
+    int q = piece % PPO, pix = (piece / PPO) % NPX, o = piece / (PPO * NPX);
+    xinfo[i] = (o & 0xff) | ((pix / IW) << 8) | ((pix % IW) << 16) | (q << 24);
+    xl_[i] = piece < XP ? (o * PSX + pix) * PPO + q : -1;
+  }
+  int ginfo[NGS], gl_[NGS];
+#pragma unroll
+  for (int i = 0; i < NGS; ++i) {
+    int piece = tid + i * 256;
+    int q = piece % PPO, pix = (piece / PPO) % TPIX, o = piece / (PPO * TPIX);
+    ginfo[i] = (o & 0xff) | ((pix >> LTW) << 8) | ((pix & (TW - 1)) << 16) | (q << 24);
+    gl_[i] = piece < GP ? (o * PSG + pix) * PPO + q : -1;
+  }
+  uint4 xr[NXS], gr[NGS];
+  auto load_regs = [&](int tile) {
     const int b = tile / tiles_per_img;
     const int tr = tile % tiles_per_img;
     const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
-    const T* xb = xbase + (long)b * p.x_is;
-    const T* gb = gbase + (long)b * p.gy_is;
-
-    uint4 xr[NXS], gr[NGS];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(xbase + (long)b * p.x_is), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(gbase + (long)b * p.gy_is), 0, (int)gbytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
-      int piece = tid + i * 256;
-      int q = piece % PPO;
-      int pix = (piece / PPO) % NPX;
-      int o = piece / (PPO * NPX);
-      int gy_ = iy0 + pix / IW, gx_ = ix0 + pix % IW;
-      bool ok = piece < XP && o < x_noct && gy_ >= 0 && gy_ < p.H && gx_ >= 0 && gx_ < p.W;
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(xb + (long)o * plane_x + ((long)gy_ * p.W + gx_) * 8 + q * EPP)
-                 : make_uint4(0, 0, 0, 0);
+      const int o = xinfo[i] & 0xff, q = xinfo[i] >> 24;
+      int gy_ = iy0 + ((xinfo[i] >> 8) & 0xff), gx_ = ix0 + ((xinfo[i] >> 16) & 0xff);
+      bool ok = xl_[i] >= 0 && gy_ >= 0 && gy_ < p.H && gx_ >= 0 && gx_ < p.W;
+      unsigned vo = ok ? (unsigned)((o * plane_x + ((long)gy_ * p.W + gx_) * 8 + q * EPP) * (long)sizeof(T)) : OOB;
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0);
+      xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 #pragma unroll
     for (int i = 0; i < NGS; ++i) {
-      int piece = tid + i * 256;
-      int q = piece % PPO;
-      int pix = (piece / PPO) % TPIX;
-      int o = piece / (PPO * TPIX);
-      int oy = oy0 + (pix >> LTW), ox = ox0 + (pix & (TW - 1));
-      bool ok = piece < GP && o < gy_noct && oy < p.OH && ox < p.OW;
-      gr[i] = ok ? *reinterpret_cast<const uint4*>(gb + (long)o * plane_g + ((long)oy * p.OW + ox) * 8 + q * EPP)
-                 : make_uint4(0, 0, 0, 0);
+      const int o = ginfo[i] & 0xff, q = ginfo[i] >> 24;
+      int oy = oy0 + ((ginfo[i] >> 8) & 0xff), ox = ox0 + ((ginfo[i] >> 16) & 0xff);
+      bool ok = gl_[i] >= 0 && oy < p.OH && ox < p.OW;
+      unsigned vo = ok ? (unsigned)((o * plane_g + ((long)oy * p.OW + ox) * 8 + q * EPP) * (long)sizeof(T)) : OOB;
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grs, vo, 0, 0);
+      gr[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
-    __syncthreads();          // previous tile fully consumed
+  };
+  auto store_lds = [&](int stage) {
+    uint4* sx = smem + stage * STAGE;
+    uint4* sg = sx + 8 * PSX * PPO;
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      int piece = tid + i * 256;
-      if (piece < XP) sx[piece] = xr[i];
-    }
+    for (int i = 0; i < NXS; ++i)
+      if (xl_[i] >= 0) sx[xl_[i]] = xr[i];
 #pragma unroll
-    for (int i = 0; i < NGS; ++i) {
-      int piece = tid + i * 256;
-      if (piece < GP) sg[piece] = gr[i];
-    }
-    __syncthreads();
+    for (int i = 0; i < NGS; ++i)
+      if (gl_[i] >= 0) sg[gl_[i]] = gr[i];
+  };
 
+  int tile = slice;
+  if (tile < ntiles) {
+    load_regs(tile);
+    store_lds(0);
+  }
+  __syncthreads();
+  int stage = 0;
+  for (; tile < ntiles; tile += p.nslices) {
+    const bool more = tile + p.nslices < ntiles;
+    if (more) load_regs(tile + p.nslices);
+    const char* sxb = reinterpret_cast<const char*>(smem + stage * STAGE);
+    const char* sgb = sxb + 8 * PSX * PPO * 16;
     if (active) {
+      if constexpr (ROWREUSE) {
+        constexpr int NC = TW / 16;           // k-steps per tile row
+        frag_t gf[TH][NC];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        // pixel offset of k-step ks relative to k-step 0 (16 pixels further in tile order)
-        constexpr int dummy = 0; (void)dummy;
-        const int tp0 = ks * 16;
-        int gofs, xofs;
-        if constexpr (LTW >= 4) {     // 16 pixels stay inside one tile row
-          const int py = tp0 >> LTW, px = tp0 & (TW - 1);
-          gofs = tp0 * OB;
-          xofs = (py * STRIDE * IW + px * STRIDE) * OB;
-        } else {                      // TW == 8: a k-step spans two rows; k-step ks starts at row 2*ks
-          gofs = tp0 * OB;
-          xofs = (2 * ks) * STRIDE * IW * OB;
+        for (int y = 0; y < TH; ++y)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            gf[y][c] = load_g(sgb, y * NC + c);
+            if (do_bias) mma(gf[y][c], ones, accb);
+          }
+        if (outp != nullptr) {
+#pragma unroll
+          for (int ry = 0; ry < IH; ++ry)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              frag_t xf[3];
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) xf[dx] = load_x(sxb, ry, c * 16 + dx);
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int y = ry - dy;
+                if (y >= 0 && y < TH) {
+#pragma unroll
+                  for (int dx = 0; dx < 3; ++dx) mma(gf[y][c], xf[dx], acc[dy * 3 + dx]);
+                }
+              }
+            }
         }
-        frag_t gf;
-        if constexpr (sizeof(T) == 2) {
-          gf = tr_frag(sgb, ga[0] + gofs, ga[1] + gofs);
-        } else {
+      } else {
 #pragma unroll
-          for (int s = 0; s < 8; ++s)
-            gf[s] = *reinterpret_cast<const float*>(sgb + ga[0] + gofs + 2 * s * OB);
-        }
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const int tp0 = ks * 16;
+          int row0, col0;
+          if constexpr (LTW >= 4) { row0 = (tp0 >> LTW) * STRIDE; col0 = (tp0 & (TW - 1)) * STRIDE; }
+          else { row0 = 2 * ks * STRIDE; col0 = 0; }     // TW == 8: a k-step is two tile rows
+          frag_t gf = load_g(sgb, ks);
+          if (do_bias) mma(gf, ones, accb);
+          if (outp != nullptr) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int dy = tap / KS, dx = tap % KS;
-          const int tofs = (dy * IW + dx) * OB;
-          frag_t xf;
-          if constexpr (sizeof(T) == 2) {
-            xf = tr_frag(sxb, xa[0] + xofs + tofs, xa[1] + xofs + tofs);
-          } else {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              // pixel 2s+h of the k-step: for TW >= 16 it is in the same row
-              int po;
-              if constexpr (LTW >= 4) po = 2 * s * STRIDE * OB;
-              else po = (((2 * s) >> 3) * STRIDE * IW + ((2 * s) & 7) * STRIDE) * OB;
-              xf[s] = *reinterpret_cast<const float*>(sxb + xa[0] + xofs + tofs + po);
+            for (int tap = 0; tap < TAPS; ++tap) {
+              frag_t xf = load_x(sxb, row0 + tap / KS, col0 + tap % KS);
+              mma(gf, xf, acc[tap]);
             }
           }
-          mma(gf, xf, acc[tap]);
         }
       }
     }
+    if (more) store_lds(stage ^ 1);
+    __syncthreads();
+    stage ^= 1;
   }
 
   if (!active) return;
   const int col = lane & 31, hh = lane >> 5;
+  if (do_bias && col == 0) {
+    const int bn = tkp->bias_n[sb], b0 = tkp->bias_co0[sb];
+    const float bs = tkp->bias_scale[sb];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = b0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (co < bn) atomicAdd(biasp + co, accb[i] * bs);
+    }
+  }
+  if (outp == nullptr) return;
   const int ld = tkp->ld[sa + 2 * sb], co_n = tkp->co_n[sa + 2 * sb];
   const int ci = tkp->ci0[sa + 2 * sb] + col;
   const int co_base = tkp->co0[sa + 2 * sb];
@@ -227,7 +320,7 @@ int launch(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
   constexpr int TW = 1 << LTW, TH = TPIX >> LTW;
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
   constexpr int PPO = Oct<T>::PPO;
-  constexpr int LDS = (8 * IH * IW * PPO + 8 * TPIX * PPO) * 16;
+  constexpr int LDS = 2 * (8 * pad4mod8(IH * IW) + 8 * pad4mod8(TPIX)) * PPO * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(TH >= 1, "tile");
   p.tiles_x = (p.OW + TW - 1) / TW;
@@ -252,13 +345,13 @@ int dispatch(const srx_wgrad_desc* d, const WgradParams& p, hipStream_t s) {
   constexpr bool F = sizeof(T) == 4;
   if (d->ksize == 1) return launch<T, 1, 5, 1, 128>(d, p, s);
   if (d->stride == 1) {
-    if (p.OW >= 24) return launch<T, 1, 5, 3, 128>(d, p, s);
-    if (p.OW >= 12) return launch<T, 1, 4, 3, 128>(d, p, s);
-    return launch<T, 1, 3, 3, 128>(d, p, s);
+    if (p.OW >= 24) return launch<T, 1, 5, 3, F ? 64 : 128>(d, p, s);
+    if (p.OW >= 12) return launch<T, 1, 4, 3, F ? 64 : 128>(d, p, s);
+    return launch<T, 1, 3, 3, F ? 64 : 128>(d, p, s);
   }
-  if (p.OW >= 24) return launch<T, 2, 5, 3, F ? 32 : 128>(d, p, s);
-  if (p.OW >= 12) return launch<T, 2, 4, 3, F ? 32 : 128>(d, p, s);
-  return launch<T, 2, 3, 3, F ? 32 : 128>(d, p, s);
+  if (p.OW >= 24) return launch<T, 2, 5, 3, F ? 32 : 64>(d, p, s);
+  if (p.OW >= 12) return launch<T, 2, 4, 3, F ? 32 : 64>(d, p, s);
+  return launch<T, 2, 3, 3, F ? 32 : 64>(d, p, s);
 }
 
 }  // namespace
@@ -270,7 +363,7 @@ extern "C" int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream) {
   SRX_CHECK_ARG(d->stride == 1 || (d->stride == 2 && d->ksize == 3), "srx_conv2d_wgrad: bad stride %d", d->stride);
   SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->ntasks > 0 && d->nslices > 0,
                 "srx_conv2d_wgrad: non-positive size");
-  SRX_CHECK_ARG(d->x && d->gy && d->tasks, "srx_conv2d_wgrad: null pointer");
+  SRX_CHECK_ARG(d->tasks, "srx_conv2d_wgrad: null task table");
   WgradParams p;
   p.x = d->x; p.x_is = d->x_img_stride;
   p.gy = d->gy; p.gy_is = d->gy_img_stride;

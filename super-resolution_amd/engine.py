@@ -243,19 +243,25 @@ class Plan:
     # ------------------------------------------------------------- wgrad
     @staticmethod
     def wgrad_tasks_for_layer(cin: int, cout: int, x_oct0: int, gy_oct0: int, out_ptr: int,
-                              scale: float = 1.0) -> List[dict]:
+                              scale: float = 1.0, bias_ptr: int = 0, x_ptr: int = 0, gy_ptr: int = 0) -> List[dict]:
         """64x64 block tasks of one convolution's weight gradient.
-        out_ptr: tap-major fp32 [taps][cout][cin] tensor."""
+        out_ptr: tap-major fp32 [taps][cout][cin] tensor; bias_ptr: fp32 [cout] or 0;
+        x_ptr / gy_ptr: image-0 base pointers of the views (0: the launch descriptor's)."""
         tasks = []
         for cj in range(_ceil(cout, 64)):
             for ci in range(_ceil(cin, 64)):
-                t = {"x_oct": x_oct0 + ci * 8, "gy_oct": gy_oct0 + cj * 8,
+                t = {"x": x_ptr, "gy": gy_ptr, "x_oct": x_oct0 + ci * 8, "gy_oct": gy_oct0 + cj * 8,
                      "x_noct": min(8, _ceil(cin, 8) - ci * 8), "gy_noct": min(8, _ceil(cout, 8) - cj * 8),
-                     "sub": {}}
-                for a in (0, 1):
-                    for b in (0, 1):
-                        ci0, co0 = ci * 64 + a * 32, cj * 64 + b * 32
-                        if ci0 < cin and co0 < cout:
+                     "sub": {}, "bias": {}}
+                for b in (0, 1):
+                    co0 = cj * 64 + b * 32
+                    if co0 >= cout:
+                        continue
+                    if ci == 0 and bias_ptr:
+                        t["bias"][b] = dict(out=bias_ptr, co0=co0, n=cout, scale=scale)
+                    for a in (0, 1):
+                        ci0 = ci * 64 + a * 32
+                        if ci0 < cin:
                             t["sub"][a + 2 * b] = dict(out=out_ptr, ld=cin, co_n=cout, ci0=ci0, co0=co0,
                                                        scale=scale)
                 tasks.append(t)
@@ -263,37 +269,51 @@ class Plan:
 
     @staticmethod
     def merge_tasks(tasks: List[dict]) -> List[dict]:
-        merged: Dict[Tuple[int, int], List[dict]] = {}
+        """Tasks that read the same (x block, gy block) pair share one workgroup as long as
+        their 32x32 sub-block slots (and bias slots) do not collide."""
+        merged: Dict[Tuple[int, int, int, int], List[dict]] = {}
         for t in tasks:
-            lst = merged.setdefault((t["x_oct"], t["gy_oct"]), [])
+            lst = merged.setdefault((t["x"], t["gy"], t["x_oct"], t["gy_oct"]), [])
             for m in lst:
-                if not (set(m["sub"]) & set(t["sub"])):
+                if not (set(m["sub"]) & set(t["sub"])) and not (set(m["bias"]) & set(t["bias"])):
                     m["sub"].update(t["sub"])
+                    m["bias"].update(t["bias"])
                     m["x_noct"] = max(m["x_noct"], t["x_noct"])
                     m["gy_noct"] = max(m["gy_noct"], t["gy_noct"])
                     break
             else:
-                lst.append({**t, "sub": dict(t["sub"])})
+                lst.append({**t, "sub": dict(t["sub"]), "bias": dict(t["bias"])})
         return [m for lst in merged.values() for m in lst]
 
-    def wgrad(self, ops: list, x: View, gy: View, tasks: List[dict], B: int, H: int, W: int, *,
-              ksize=3, stride=1, target_blocks=512):
+    def wgrad(self, ops: list, x: Optional[View], gy: Optional[View], tasks: List[dict], B: int, H: int, W: int, *,
+              ksize=3, stride=1, target_blocks=512, nslices: Optional[int] = None,
+              x_img_stride: int = 0, gy_img_stride: int = 0):
         arr = (L.WgradTask * len(tasks))()
         for i, t in enumerate(tasks):
             k = arr[i]
+            k.x, k.gy = (t.get("x") or None), (t.get("gy") or None)
             k.x_oct, k.gy_oct, k.x_noct, k.gy_noct = t["x_oct"], t["gy_oct"], t["x_noct"], t["gy_noct"]
             for s, e in t["sub"].items():
                 k.out[s] = e["out"]
                 k.ld[s], k.co_n[s], k.ci0[s], k.co0[s], k.scale[s] = e["ld"], e["co_n"], e["ci0"], e["co0"], e["scale"]
+            for b, e in t.get("bias", {}).items():
+                k.bias_out[b] = e["out"]
+                k.bias_co0[b], k.bias_n[b], k.bias_scale[b] = e["co0"], e["n"], e["scale"]
         dev = self.upload(arr)
         op = L.Op()
         op.kind = L.OP_WGRAD
         d = op.u.wgrad
         d.dtype, d.ksize, d.stride, d.B, d.H, d.W = self.dt, ksize, stride, B, H, W
-        d.x, d.x_img_stride = x[0].ptr(x[1]), x[0].img_stride
-        d.gy, d.gy_img_stride = gy[0].ptr(gy[1]), gy[0].img_stride
+        if x is not None:
+            d.x, d.x_img_stride = x[0].ptr(x[1]), x[0].img_stride
+        else:
+            d.x_img_stride = x_img_stride
+        if gy is not None:
+            d.gy, d.gy_img_stride = gy[0].ptr(gy[1]), gy[0].img_stride
+        else:
+            d.gy_img_stride = gy_img_stride
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
-        d.nslices = max(1, _ceil(target_blocks, len(tasks)))
+        d.nslices = nslices if nslices is not None else max(1, _ceil(target_blocks, len(tasks)))
         ops.append(op)
         if isinstance(ops, OpList):
             pad = ksize // 2
@@ -301,9 +321,10 @@ class Plan:
             pairs = sum(min(32, e["ld"] - e["ci0"]) * min(32, e["co_n"] - e["co0"])
                         for t in tasks for e in t["sub"].values())
             ltw = 5 if OW >= 24 else (4 if OW >= 12 else 3)
-            tp = 32 if (self.dt == L.F32 and stride == 2) else 128
-            name = "wgrad_kernel<%s,%d,%d,%d,%d>" % ("bf16" if self.dt == L.BF16 else "float",
-                                                     stride, 5 if ksize == 1 else ltw, ksize, tp)
+            f = self.dt == L.F32
+            tp = 128 if ksize == 1 else ((64 if f else 128) if stride == 1 else (32 if f else 64))
+            name = "wgrad_kernel<%s,%d,%d,%d,%d>" % ("float" if f else "bf16", stride,
+                                                     5 if ksize == 1 else ltw, ksize, tp)
             ops.meta.append((name, 2.0 * B * OH * OW * ksize * ksize * pairs))
 
     def unpack_item(self, src_ptr: int, dst_ptr: int, cout: int, cin: int, taps: int):
@@ -409,10 +430,9 @@ class _GenBase(Plan):
 
     def layer_wgrad(self, ops, P, name, x: View, gy: View, B, Hh, Ww):
         wt = P[name + ".weight"]
-        tasks = self.wgrad_tasks_for_layer(wt.shape[1], wt.shape[0], 0, 0, self.sp(name + ".weight"))
+        tasks = self.wgrad_tasks_for_layer(wt.shape[1], wt.shape[0], 0, 0, self.sp(name + ".weight"),
+                                           bias_ptr=self.sp(name + ".bias"))
         self.wgrad(ops, x, gy, tasks, B, Hh, Ww)
-        self.generic(ops, L.OP_CHANNEL_SUM, a=gy, c_ptr=self.sp(name + ".bias"), B=B, H=Hh, W=Ww,
-                     noct=_ceil(wt.shape[0], 8), f0=1.0)
 
     # ---- dense block ------------------------------------------------------
     def emit_rdb_fwd(self, ops, P, pre, cur: Buf, dst: View, B, h, w, nf, gc, q,
@@ -433,7 +453,7 @@ class _GenBase(Plan):
                       alpha=RES * RES, res1=(cur, 0), beta1=RES, res2=rrdb_in, beta2=1.0)
 
     def emit_rdb_bwd(self, ops, P, pre, cur: Buf, G: Buf, dst: View, B, h, w, nf, gc, q,
-                     rrdb_g: Optional[View]):
+                     rrdb_g: Optional[View], defer_wgrad: Optional[list] = None):
         """Backward of one dense block.  G = [gy1|gy2|gy3|gy4|g_out]; g_out (the gradient
         of the block output, or of the RRDB output when q == 2) must already be in place.
         dst receives the gradient of the block input (+ the RRDB skip gradient rrdb_g when
@@ -459,14 +479,19 @@ class _GenBase(Plan):
             else:
                 self.conv(ops, xin, dst, wp, 0, B, h, w, c0, nf, res1=(G, g8),
                           beta1=(RES if q == 2 else 1.0))
+        # weight + bias gradients of the five convolutions: one launch per block, or deferred
+        # into a single launch for the whole trunk (tasks then carry their own buffer pointers)
         tasks = []
+        xp, gp = (cur.ptr(0), G.ptr(0)) if defer_wgrad is not None else (0, 0)
         for k in range(1, 6):
             tasks += self.wgrad_tasks_for_layer(nf + (k - 1) * gc, gc if k < 5 else nf, 0, (k - 1) * gc8,
-                                                self.sp(pre + f"conv{k}.weight"), s5 if k == 5 else 1.0)
-        self.wgrad(ops, (cur, 0), (G, 0), self.merge_tasks(tasks), B, h, w)
-        for k in range(1, 6):
-            self.generic(ops, L.OP_CHANNEL_SUM, a=(G, (k - 1) * gc8), c_ptr=self.sp(pre + f"conv{k}.bias"),
-                         B=B, H=h, W=w, noct=(gc8 if k < 5 else nf8), f0=(s5 if k == 5 else 1.0))
+                                                self.sp(pre + f"conv{k}.weight"), s5 if k == 5 else 1.0,
+                                                bias_ptr=self.sp(pre + f"conv{k}.bias"), x_ptr=xp, gy_ptr=gp)
+        tasks = self.merge_tasks(tasks)
+        if defer_wgrad is not None:
+            defer_wgrad.extend(tasks)
+        else:
+            self.wgrad(ops, (cur, 0), (G, 0), tasks, B, h, w)
 
     # ---- shared run API ---------------------------------------------------
     def backward_c8(self) -> None:
@@ -480,6 +505,8 @@ class GeneratorPlan(_GenBase):
     params: name -> fp32 CUDA tensor with the reference's state_dict names.
     After backward, ``grads[name]`` are fp32 views of one flat buffer in parameter order.
     """
+
+    trunk_wgrad_slices = 4
 
     def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
                  *, in_ch=3, out_ch=3, nf=64, gc=32, num_blocks=23, need_grad=True,
@@ -578,11 +605,17 @@ class GeneratorPlan(_GenBase):
         self.layer_wgrad(bwd, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w)
         last_dst = (self.G[nR - 1], g8) if nR else (self.gfeat, 0)
         self.conv(bwd, (self.gT1, 0), last_dst, self.dgrad_layer(P, "conv_body", nf), 0, B, h, w, nf, nf)
+        trunk_tasks: list = []
         for r in range(nR - 1, -1, -1):
             blk, q = divmod(r, 3)
             dst = (self.G[r - 1], g8) if r > 0 else (self.gfeat, 0)
             self.emit_rdb_bwd(bwd, P, f"body.{blk}.rdb{q + 1}.", Rb(r), self.G[r], dst, B, h, w, nf, gc, q,
-                              (self.G[r + 2], g8) if q == 0 else None)
+                              (self.G[r + 2], g8) if q == 0 else None, defer_wgrad=trunk_tasks)
+        if trunk_tasks:
+            # every dense block's weight gradients in ONE launch: long-running workgroups, few
+            # pixel slices (little atomic traffic), block order keeps one block's buffers hot
+            self.wgrad(bwd, None, None, trunk_tasks, B, h, w, nslices=self.trunk_wgrad_slices,
+                       x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride)
         # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
         self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
                      n=self.gfeat.t.numel())
