@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   constexpr int NWS = (WP + 255) / 256;
   constexpr int STAGE = XP + WP;            // pieces per stage
 
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,22 +122,22 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   }
 
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  uint4 xr[NXS], wr[NWS];
+  u32x4 xr[NXS], wr[NWS];
   auto load_regs = [&](int chunk) {
     const unsigned coff = (unsigned)chunk * 2u * plane_bytes;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       unsigned vo = ((xok >> i) & 1) ? xoff[i] + coff : OOB;
       u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0);
-      xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
+      xr[i] = v;
     }
     const T* wc = wb + (long)chunk * (TAPS * 512);
 #pragma unroll
-    for (int i = 0; i < NWS; ++i) wr[i] = *reinterpret_cast<const uint4*>(wc + woff[i]);
+    for (int i = 0; i < NWS; ++i) wr[i] = *reinterpret_cast<const u32x4*>(wc + woff[i]);
   };
   auto store_lds = [&](int stage) {
-    uint4* sx = smem + stage * STAGE;
-    uint4* sw = sx + XP;
+    u32x4* sx = smem + stage * STAGE;
+    u32x4* sw = sx + XP;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       int piece = tid + i * 256;
