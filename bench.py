@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--streams", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +116,7 @@ def main():
     gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
     B, h = args.batch, args.patch
     sync = D.FlatGradAllReduce(world) if world > 1 else None
-    trainer = T.GeneratorWarmupTrainer(gen, (B, 3, h, h), torch.bfloat16, grad_sync=sync)
+    trainer = T.GeneratorWarmupTrainer(gen, (B, 3, h, h), torch.bfloat16, grad_sync=sync, n_streams=args.streams)
     gcpu = torch.Generator().manual_seed(1234 + rank)
     lr = (torch.rand((B, 3, h, h), generator=gcpu) * 2 - 1).to(dev)
     hr = (torch.rand((B, 3, 4 * h, 4 * h), generator=gcpu) * 2 - 1).to(dev)

@@ -122,6 +122,7 @@ class Plan:
     def buf(self, B, C_, H, W, zero=False) -> Buf:
         b = Buf(B, C_, H, W, self.tdtype, self.device, zero)
         self.bytes_alloc += b.nbytes
+        self.keep.append(b.t)      # op descriptors hold raw pointers: the plan owns the memory
         return b
 
     def f32(self, n: int, zero=True) -> torch.Tensor:
@@ -327,9 +328,12 @@ class Plan:
                                                      5 if ksize == 1 else ltw, ksize, tp)
             ops.meta.append((name, 2.0 * B * OH * OW * ksize * ksize * pairs))
 
+    unpack_accumulate = 0    # 1: run_unpack adds into the destination gradients
+
     def unpack_item(self, src_ptr: int, dst_ptr: int, cout: int, cin: int, taps: int):
         it = L.UnpackItem()
-        it.src, it.dst, it.cout, it.cin, it.taps, it.accumulate = src_ptr, dst_ptr, cout, cin, taps, 0
+        it.src, it.dst, it.cout, it.cin, it.taps = src_ptr, dst_ptr, cout, cin, taps
+        it.accumulate = self.unpack_accumulate
         self.unpack_items.append(it)
         self.unpack_max = max(self.unpack_max, cout * cin * taps)
 
@@ -510,9 +514,11 @@ class GeneratorPlan(_GenBase):
 
     def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
                  *, in_ch=3, out_ch=3, nf=64, gc=32, num_blocks=23, need_grad=True,
-                 need_input_grad=False, flat_grad: Optional[torch.Tensor] = None):
+                 need_input_grad=False, flat_grad: Optional[torch.Tensor] = None,
+                 accumulate_grads: bool = False):
         dev = params["conv_first.weight"].device
         super().__init__(dev, tdtype)
+        self.unpack_accumulate = 1 if accumulate_grads else 0
         if nf % 8 or gc % 8:
             raise ValueError("num_features and growth channels must be multiples of 8")
         self.B, self.h, self.w = B, h, w
