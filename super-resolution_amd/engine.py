@@ -248,25 +248,28 @@ class Plan:
         """64x64 block tasks of one convolution's weight gradient.
         out_ptr: tap-major fp32 [taps][cout][cin] tensor; bias_ptr: fp32 [cout] or 0;
         x_ptr / gy_ptr: image-0 base pointers of the views (0: the launch descriptor's)."""
-        tasks = []
-        for cj in range(_ceil(cout, 64)):
+        tasks: Dict[Tuple[int, int], dict] = {}
+        aligned = gy_oct0 % 4 == 0       # 32-channel blocks of the view line up with the 64-wide tasks
+        for co32 in range(_ceil(cout, 32)):
+            if aligned:
+                blk = gy_oct0 // 4 + co32
+                gy_oct, b = (blk // 2) * 8, blk % 2
+            else:
+                gy_oct, b = gy_oct0 + (co32 // 2) * 8, co32 % 2
+            co0 = co32 * 32
+            noct_g = 4 * b + min(4, _ceil(cout, 8) - co32 * 4)
             for ci in range(_ceil(cin, 64)):
-                t = {"x": x_ptr, "gy": gy_ptr, "x_oct": x_oct0 + ci * 8, "gy_oct": gy_oct0 + cj * 8,
-                     "x_noct": min(8, _ceil(cin, 8) - ci * 8), "gy_noct": min(8, _ceil(cout, 8) - cj * 8),
-                     "sub": {}, "bias": {}}
-                for b in (0, 1):
-                    co0 = cj * 64 + b * 32
-                    if co0 >= cout:
-                        continue
-                    if ci == 0 and bias_ptr:
-                        t["bias"][b] = dict(out=bias_ptr, co0=co0, n=cout, scale=scale)
-                    for a in (0, 1):
-                        ci0 = ci * 64 + a * 32
-                        if ci0 < cin:
-                            t["sub"][a + 2 * b] = dict(out=out_ptr, ld=cin, co_n=cout, ci0=ci0, co0=co0,
-                                                       scale=scale)
-                tasks.append(t)
-        return tasks
+                t = tasks.setdefault((ci, gy_oct), {
+                    "x": x_ptr, "gy": gy_ptr, "x_oct": x_oct0 + ci * 8, "gy_oct": gy_oct,
+                    "x_noct": min(8, _ceil(cin, 8) - ci * 8), "gy_noct": 0, "sub": {}, "bias": {}})
+                t["gy_noct"] = max(t["gy_noct"], noct_g)
+                if ci == 0 and bias_ptr:
+                    t["bias"][b] = dict(out=bias_ptr, co0=co0, n=cout, scale=scale)
+                for a in (0, 1):
+                    ci0 = ci * 64 + a * 32
+                    if ci0 < cin:
+                        t["sub"][a + 2 * b] = dict(out=out_ptr, ld=cin, co_n=cout, ci0=ci0, co0=co0, scale=scale)
+        return list(tasks.values())
 
     @staticmethod
     def merge_tasks(tasks: List[dict]) -> List[dict]:
