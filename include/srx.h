@@ -148,6 +148,8 @@ typedef struct srx_wgrad_desc {
   const srx_wgrad_task* tasks;   /* DEVICE array                                   */
   int32_t ntasks;
   int32_t nslices;       /* pixel-tile slices per task (grid = ntasks*nslices)      */
+  int32_t group;         /* >1: tasks come in consecutive groups of this many that read the same
+                            buffers; used to co-locate them on one XCD (speed only)  */
 } srx_wgrad_desc;
 
 /* dW of nn.Conv2d (the autograd of esrgan/generator.py:10-14 etc.). */

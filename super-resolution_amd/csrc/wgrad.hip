@@ -10,11 +10,11 @@
 // accumulators of one 32x32 sub-block (144 registers) across all tiles of the
 // slice, then add them with fp32 atomics into tap-major gradient tensors
 // ([tap][cout][cin]: the 32 lanes of a half-wave are 32 consecutive cin, i.e.
-// 128 contiguous bytes per atomic instruction half).  The bias gradient is one
-// more MFMA per k-step against an all-ones operand.
+// 128 contiguous bytes per atomic instruction half).  The bias gradient is one more MFMA
+// per k-step against an all-ones operand, in the wave that owns that bias slice.
 //
-// Pipeline: register-staged double buffering (tile t+1's global loads are in
-// flight behind tile t's MFMAs; one barrier per tile).  For stride 1 the X
+// Pipeline: LDS-DMA double buffering (tile t+1 streams global->LDS behind tile t's
+// MFMAs without touching VGPRs; one barrier per tile).  For stride 1 the X
 // fragments of an input row are read once and used by the three taps dy that map
 // it to an output row.  Octet planes in LDS are padded to 4 (mod 8) slots so the
 // transposed reads of a 32-lane half fall on 32 distinct 8-byte banks.
@@ -28,6 +28,7 @@ struct WgradParams {
   const srx_wgrad_task* tasks;
   int H, W, OH, OW, B;
   int nslices, tiles_x, tiles_y;
+  int group, ntasks;     // tasks per group (share x/gy buffers) for XCD-local ordering; 0 = off
 };
 
 template <typename T> struct Frag;
@@ -44,6 +45,8 @@ __device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+
+
 // 8 consecutive-pixel bf16 values of one channel: two transposed 4x16 block reads.
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_base, int addr0, int addr1) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + addr0));
@@ -54,6 +57,52 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_base, int addr0, int a
 }
 
 constexpr int pad4mod8(int n) { return n + ((4 - n % 8) + 8) % 8; }
+
+// Stage one tile (X halo tile + GY tile) into LDS stage `ls` by LDS-DMA.  A free function
+// rather than a lambda: hipcc (ROCm 7.2) drops the host-side kernel stub when a by-reference
+// captured array feeds this builtin's offset operand.
+template <typename T, int STRIDE, int LTW, int KS, int TPIX, int NXS, int NGS, int XSL, int GSL>
+__device__ __forceinline__ void wgrad_stage_tile(const WgradParams& p, const T* xbase, const T* gbase,
+                                                 int tile, int tiles_per_img, char* ls, int tid, int wave_u,
+                                                 int xbytes, int gbytes, const unsigned (&xoffs)[NXS],
+                                                 const int (&xrc)[NXS], const unsigned (&goffs)[NGS],
+                                                 const int (&grc)[NGS]) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int TW = 1 << LTW, TH = TPIX >> LTW, PAD = KS / 2;
+
+    const int b = tile / tiles_per_img;
+    const int tr = tile % tiles_per_img;
+    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    // descriptors based at the tile's first input / output pixel (may lie before the plane for
+    // border tiles: those lanes are out of range by construction and never dereferenced)
+    const long xoff_b = ((long)iy0 * p.W + ix0) * 8 * (long)sizeof(T);
+    const long goff_b = ((long)oy0 * p.OW + ox0) * 8 * (long)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(xbase + (long)b * p.x_is) + xoff_b), 0,
+        (int)(xbytes - xoff_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(gbase + (long)b * p.gy_is) + goff_b), 0,
+        (int)(gbytes - goff_b), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const unsigned gy_ = (unsigned)(iy0 + (xrc[i] & 0xffff)), gx_ = (unsigned)(ix0 + (xrc[i] >> 16));
+      const bool ok = xrc[i] >= 0 && gy_ < (unsigned)p.H && gx_ < (unsigned)p.W;
+      if (NXS * 256 == XSL || tid + i * 256 < XSL)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(ls + (i * 256 + wave_u * 64) * 16), 16,
+                                                 ok ? xoffs[i] : OOB, 0, 0, 0);
+    }
+    char* lg = ls + XSL * 16;
+#pragma unroll
+    for (int i = 0; i < NGS; ++i) {
+      const unsigned oy = (unsigned)(oy0 + (grc[i] & 0xffff)), ox = (unsigned)(ox0 + (grc[i] >> 16));
+      const bool ok = grc[i] >= 0 && oy < (unsigned)p.OH && ox < (unsigned)p.OW;
+      if (NGS * 256 == GSL || tid + i * 256 < GSL)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(lg + (i * 256 + wave_u * 64) * 16), 16,
+                                                 ok ? goffs[i] : OOB, 0, 0, 0);
+    }
+  }
 
 template <typename T, int STRIDE, int LTW, int KS, int TPIX>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -69,10 +118,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int PSG = pad4mod8(TPIX);       // ... of the GY tile
   constexpr int PPO = Oct<T>::PPO;
   constexpr int EPP = 16 / sizeof(T);
-  constexpr int XP = 8 * NPX * PPO;         // pieces loaded per tile
-  constexpr int GP = 8 * TPIX * PPO;
-  constexpr int NXS = (XP + 255) / 256;
-  constexpr int NGS = (GP + 255) / 256;
   constexpr int KSTEPS = TPIX / 16;
   constexpr int OB = sizeof(T) * 8;         // bytes per octet slot
   constexpr int STAGE = (8 * PSX + 8 * PSG) * PPO;   // 16-byte pieces per stage
@@ -81,14 +126,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int task_id = blockIdx.x / p.nslices, slice = blockIdx.x % p.nslices;
+  // Block -> (task, slice).  With groups, the `group` tasks that read the same buffers for the
+  // same pixel slice get block ids that are equal mod 8 and adjacent in time, so (under the
+  // observed round-robin placement) they run on one XCD and share its L2: each byte of X / GY
+  // is then fetched from HBM/MALL about once instead of once per task.  Placement is a speed
+  // matter only; any mapping that is a bijection is correct.
+  int task_id, slice;
+  if (p.group > 0) {
+    const int gsz = p.group;
+    const int ngrp = (p.ntasks / gsz) * p.nslices;           // (buffer set, slice) pairs
+    const int super_ = blockIdx.x / (8 * gsz), r = blockIdx.x % (8 * gsz);
+    const int g = super_ * 8 + (r % 8), t = r / 8;
+    if (g >= ngrp) return;
+    task_id = (g / p.nslices) * gsz + t;
+    slice = g % p.nslices;
+  } else {
+    task_id = blockIdx.x / p.nslices;
+    slice = blockIdx.x % p.nslices;
+  }
   const srx_wgrad_task* __restrict__ tkp = p.tasks + task_id;
   const int sa = wave & 1, sb = wave >> 1;      // cin half, cout half
   float* const outp = tkp->out[sa + 2 * sb];
   float* const biasp = sa == 0 ? tkp->bias_out[sb] : nullptr;
   const int x_noct = tkp->x_noct, gy_noct = tkp->gy_noct;
-  const bool active = outp != nullptr || biasp != nullptr;     // wave-uniform
-  const bool do_bias = biasp != nullptr;
+  const bool active = outp != nullptr;          // wave-uniform
 
   const long plane_x = (long)p.H * p.W * 8;
   const long plane_g = (long)p.OH * p.OW * 8;
@@ -145,13 +206,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   };
 
   f32x16 acc[TAPS];
-  f32x16 accb;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // bias gradient: in the one wave per cout half that owns it, one extra MFMA per k-step
+  // against an all-ones operand (every column of the result is the per-channel pixel sum)
+  f32x16 accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
   frag_t ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
@@ -159,80 +222,58 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int ntiles = p.B * tiles_per_img;
 
-  // ---- staging: unconditional buffer loads (out-of-image pixels and octets beyond the
-  // task's valid range get an out-of-range offset and read as zero) ----
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  // ---- staging: LDS-DMA through a buffer descriptor (buffer_load ... lds, 16 B per lane).
+  // The LDS image of a wave instruction is lane-linear, so threads own consecutive 16-byte
+  // slots of the padded tile image; the per-lane SOURCE offset carries the layout.  A lane
+  // whose offset is out of the descriptor's range deposits zeros in LDS (measured on gfx950),
+  // which serves the zero padding, octets beyond the task's valid range and the pad slots:
+  // no load is conditional and nothing passes through VGPRs.
+  typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  const unsigned xbytes = (unsigned)x_noct * (unsigned)(plane_x * sizeof(T));
-  const unsigned gbytes = (unsigned)gy_noct * (unsigned)(plane_g * sizeof(T));
-  // per-thread piece -> (octet, tile pixel) decomposition is tile independent
-  // packed per-piece info: octet | row << 8 | col << 16 | q << 24 ; LDS piece index (or -1)
-  int xinfo[NXS], xl_[NXS];
+  constexpr int XSL = 8 * PSX * PPO, GSL = 8 * PSG * PPO;       // slots per stage (incl. pads)
+  constexpr int NXS = (XSL + 255) / 256, NGS = (GSL + 255) / 256;
+  const unsigned xplane_b = (unsigned)(plane_x * sizeof(T)), gplane_b = (unsigned)(plane_g * sizeof(T));
+  const int xbytes = (int)((unsigned)x_noct * xplane_b), gbytes = (int)((unsigned)gy_noct * gplane_b);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // per-slot constants: byte offset from the tile's first input pixel, and (row, col) for the
+  // bounds test; rc < 0 marks a slot that always reads zeros
+  unsigned xoffs[NXS], goffs[NGS];
+  int xrc[NXS], grc[NGS];
 #pragma unroll
   for (int i = 0; i < NXS; ++i) {
-    int piece = tid + i * 256;
-    int q = piece % PPO, pix = (piece / PPO) % NPX, o = piece / (PPO * NPX);
-    xinfo[i] = (o & 0xff) | ((pix / IW) << 8) | ((pix % IW) << 16) | (q << 24);
-    xl_[i] = piece < XP ? (o * PSX + pix) * PPO + q : -1;
+    int slot = tid + i * 256;
+    int q = slot % PPO, pix = (slot / PPO) % PSX, o = slot / (PPO * PSX);
+    int r = pix / IW, c = pix % IW;
+    bool live = slot < XSL && pix < NPX && o < x_noct;
+    xoffs[i] = (unsigned)o * xplane_b + (unsigned)(((r * p.W + c) * 8 + q * EPP) * (int)sizeof(T));
+    xrc[i] = live ? (r | (c << 16)) : -1;
   }
-  int ginfo[NGS], gl_[NGS];
 #pragma unroll
   for (int i = 0; i < NGS; ++i) {
-    int piece = tid + i * 256;
-    int q = piece % PPO, pix = (piece / PPO) % TPIX, o = piece / (PPO * TPIX);
-    ginfo[i] = (o & 0xff) | ((pix >> LTW) << 8) | ((pix & (TW - 1)) << 16) | (q << 24);
-    gl_[i] = piece < GP ? (o * PSG + pix) * PPO + q : -1;
+    int slot = tid + i * 256;
+    int q = slot % PPO, pix = (slot / PPO) % PSG, o = slot / (PPO * PSG);
+    int r = pix >> LTW, c = pix & (TW - 1);
+    bool live = slot < GSL && pix < TPIX && o < gy_noct;
+    goffs[i] = (unsigned)o * gplane_b + (unsigned)(((r * p.OW + c) * 8 + q * EPP) * (int)sizeof(T));
+    grc[i] = live ? (r | (c << 16)) : -1;
   }
-  uint4 xr[NXS], gr[NGS];
-  auto load_regs = [&](int tile) {
-    const int b = tile / tiles_per_img;
-    const int tr = tile % tiles_per_img;
-    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(xbase + (long)b * p.x_is), 0, (int)xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(gbase + (long)b * p.gy_is), 0, (int)gbytes, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      const int o = xinfo[i] & 0xff, q = xinfo[i] >> 24;
-      int gy_ = iy0 + ((xinfo[i] >> 8) & 0xff), gx_ = ix0 + ((xinfo[i] >> 16) & 0xff);
-      bool ok = xl_[i] >= 0 && gy_ >= 0 && gy_ < p.H && gx_ >= 0 && gx_ < p.W;
-      unsigned vo = ok ? (unsigned)((o * plane_x + ((long)gy_ * p.W + gx_) * 8 + q * EPP) * (long)sizeof(T)) : OOB;
-      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0);
-      xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
-    }
-#pragma unroll
-    for (int i = 0; i < NGS; ++i) {
-      const int o = ginfo[i] & 0xff, q = ginfo[i] >> 24;
-      int oy = oy0 + ((ginfo[i] >> 8) & 0xff), ox = ox0 + ((ginfo[i] >> 16) & 0xff);
-      bool ok = gl_[i] >= 0 && oy < p.OH && ox < p.OW;
-      unsigned vo = ok ? (unsigned)((o * plane_g + ((long)oy * p.OW + ox) * 8 + q * EPP) * (long)sizeof(T)) : OOB;
-      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grs, vo, 0, 0);
-      gr[i] = make_uint4(v[0], v[1], v[2], v[3]);
-    }
-  };
-  auto store_lds = [&](int stage) {
-    uint4* sx = smem + stage * STAGE;
-    uint4* sg = sx + 8 * PSX * PPO;
-#pragma unroll
-    for (int i = 0; i < NXS; ++i)
-      if (xl_[i] >= 0) sx[xl_[i]] = xr[i];
-#pragma unroll
-    for (int i = 0; i < NGS; ++i)
-      if (gl_[i] >= 0) sg[gl_[i]] = gr[i];
+  // tiles of this slice: a contiguous range, walked with (image, tile row, tile col) counters
+  const int per_slice = (ntiles + p.nslices - 1) / p.nslices;
+  const int t_begin = slice * per_slice;
+  const int t_end = t_begin + per_slice < ntiles ? t_begin + per_slice : ntiles;
+  auto stage_tile = [&](int tile, int stage) {
+    wgrad_stage_tile<T, STRIDE, LTW, KS, TPIX, NXS, NGS, XSL, GSL>(
+        p, xbase, gbase, tile, tiles_per_img, reinterpret_cast<char*>(smem + stage * STAGE), tid, wave_u,
+        xbytes, gbytes, xoffs, xrc, goffs, grc);
   };
 
-  int tile = slice;
-  if (tile < ntiles) {
-    load_regs(tile);
-    store_lds(0);
-  }
-  __syncthreads();
+  int tile = t_begin;
+  if (tile < t_end) stage_tile(tile, 0);
+  __syncthreads();            // (the compiler drains the DMA, vmcnt(0), ahead of the barrier)
   int stage = 0;
-  for (; tile < ntiles; tile += p.nslices) {
-    const bool more = tile + p.nslices < ntiles;
-    if (more) load_regs(tile + p.nslices);
+  for (; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) stage_tile(tile + 1, stage ^ 1);
     const char* sxb = reinterpret_cast<const char*>(smem + stage * STAGE);
     const char* sgb = sxb + 8 * PSX * PPO * 16;
     if (active) {
@@ -242,28 +283,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int y = 0; y < TH; ++y)
 #pragma unroll
+          for (int c = 0; c < NC; ++c) gf[y][c] = load_g(sgb, y * NC + c);
+        if (biasp != nullptr) {               // wave-uniform: one wave in ~6 owns a bias slice
+#pragma unroll
+          for (int y = 0; y < TH; ++y)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mma(gf[y][c], ones, accb);
+        }
+#pragma unroll
+        for (int ry = 0; ry < IH; ++ry)
+#pragma unroll
           for (int c = 0; c < NC; ++c) {
-            gf[y][c] = load_g(sgb, y * NC + c);
-            if (do_bias) mma(gf[y][c], ones, accb);
-          }
-        if (outp != nullptr) {
+            frag_t xf[3];
 #pragma unroll
-          for (int ry = 0; ry < IH; ++ry)
+            for (int dx = 0; dx < 3; ++dx) xf[dx] = load_x(sxb, ry, c * 16 + dx);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              frag_t xf[3];
+            for (int dy = 0; dy < 3; ++dy) {
+              const int y = ry - dy;
+              if (y >= 0 && y < TH) {
 #pragma unroll
-              for (int dx = 0; dx < 3; ++dx) xf[dx] = load_x(sxb, ry, c * 16 + dx);
-#pragma unroll
-              for (int dy = 0; dy < 3; ++dy) {
-                const int y = ry - dy;
-                if (y >= 0 && y < TH) {
-#pragma unroll
-                  for (int dx = 0; dx < 3; ++dx) mma(gf[y][c], xf[dx], acc[dy * 3 + dx]);
-                }
+                for (int dx = 0; dx < 3; ++dx) mma(gf[y][c], xf[dx], acc[dy * 3 + dx]);
               }
             }
-        }
+          }
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -272,25 +314,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
           if constexpr (LTW >= 4) { row0 = (tp0 >> LTW) * STRIDE; col0 = (tp0 & (TW - 1)) * STRIDE; }
           else { row0 = 2 * ks * STRIDE; col0 = 0; }     // TW == 8: a k-step is two tile rows
           frag_t gf = load_g(sgb, ks);
-          if (do_bias) mma(gf, ones, accb);
-          if (outp != nullptr) {
+          if (biasp != nullptr) mma(gf, ones, accb);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-              frag_t xf = load_x(sxb, row0 + tap / KS, col0 + tap % KS);
-              mma(gf, xf, acc[tap]);
-            }
+          for (int tap = 0; tap < TAPS; ++tap) {
+            frag_t xf = load_x(sxb, row0 + tap / KS, col0 + tap % KS);
+            mma(gf, xf, acc[tap]);
           }
         }
       }
     }
-    if (more) store_lds(stage ^ 1);
     __syncthreads();
     stage ^= 1;
   }
 
   if (!active) return;
   const int col = lane & 31, hh = lane >> 5;
-  if (do_bias && col == 0) {
+  if (biasp != nullptr && col == 0) {
     const int bn = tkp->bias_n[sb], b0 = tkp->bias_co0[sb];
     const float bs = tkp->bias_scale[sb];
 #pragma unroll
@@ -299,7 +338,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       if (co < bn) atomicAdd(biasp + co, accb[i] * bs);
     }
   }
-  if (outp == nullptr) return;
   const int ld = tkp->ld[sa + 2 * sb], co_n = tkp->co_n[sa + 2 * sb];
   const int ci = tkp->ci0[sa + 2 * sb] + col;
   const int co_base = tkp->co0[sa + 2 * sb];
@@ -335,6 +373,12 @@ int launch(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
   long ntiles = (long)p.B * p.tiles_x * p.tiles_y;
   if (p.nslices > ntiles) p.nslices = (int)ntiles;
   long grid = (long)d->ntasks * p.nslices;
+  p.group = 0; p.ntasks = d->ntasks;
+  if (d->group > 1 && d->ntasks % d->group == 0) {
+    p.group = d->group;
+    long ngrp = (long)(d->ntasks / d->group) * p.nslices;
+    grid = ((ngrp + 7) / 8) * 8 * d->group;
+  }
   SRX_CHECK_ARG(grid > 0 && grid < (1L << 31), "wgrad grid out of range");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
   return srx_check_launch("wgrad_kernel");
@@ -374,6 +418,7 @@ extern "C" int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream) {
   p.OW = (d->W + 2 * pad - d->ksize) / d->stride + 1;
   p.nslices = d->nslices;
   p.tiles_x = p.tiles_y = 0;
+  p.group = 0; p.ntasks = d->ntasks;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == SRX_BF16 ? dispatch<bf16>(d, p, s) : dispatch<float>(d, p, s);
 }

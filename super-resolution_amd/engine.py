@@ -291,7 +291,7 @@ class Plan:
 
     def wgrad(self, ops: list, x: Optional[View], gy: Optional[View], tasks: List[dict], B: int, H: int, W: int, *,
               ksize=3, stride=1, target_blocks=512, nslices: Optional[int] = None,
-              x_img_stride: int = 0, gy_img_stride: int = 0):
+              x_img_stride: int = 0, gy_img_stride: int = 0, group: int = 0):
         arr = (L.WgradTask * len(tasks))()
         for i, t in enumerate(tasks):
             k = arr[i]
@@ -318,6 +318,7 @@ class Plan:
             d.gy_img_stride = gy_img_stride
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
         d.nslices = nslices if nslices is not None else max(1, _ceil(target_blocks, len(tasks)))
+        d.group = group
         ops.append(op)
         if isinstance(ops, OpList):
             pad = ksize // 2
@@ -623,8 +624,10 @@ class GeneratorPlan(_GenBase):
         if trunk_tasks:
             # every dense block's weight gradients in ONE launch: long-running workgroups, few
             # pixel slices (little atomic traffic), block order keeps one block's buffers hot
+            per_block = len(trunk_tasks) // nR
             self.wgrad(bwd, None, None, trunk_tasks, B, h, w, nslices=self.trunk_wgrad_slices,
-                       x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride)
+                       x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
+                       group=per_block if per_block * nR == len(trunk_tasks) else 0)
         # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
         self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
                      n=self.gfeat.t.numel())
