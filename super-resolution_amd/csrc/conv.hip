@@ -8,9 +8,9 @@
 // every LDS fragment read is one 16-byte slot per lane.
 //
 // One workgroup = 4 waves = (4*RW) groups of 32 output pixels x (32*NB) couts.
-// K loop over 16-channel chunks, register-staged double buffering: the global
-// loads of chunk c+1 are issued before the MFMAs of chunk c and written to the
-// other LDS stage afterwards (one barrier per chunk).
+// K loop over 16-channel chunks through a 3-stage LDS ring filled by LDS-DMA
+// (buffer_load ... lds): chunk c+2 streams in while chunk c is multiplied; one
+// counted s_waitcnt vmcnt + one raw s_barrier per chunk.
 //
 // Epilogue (bias, derivative mask, LeakyReLU/ReLU, residual scaling, optional
 // PixelShuffle(2) scatter) runs on the accumulators; the weight packer orders
@@ -46,6 +46,25 @@ __device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
   for (int s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
 }
 
+// Issue one chunk's LDS-DMA: NXS activation + NWS weight instructions per wave, no branches.
+template <typename T, int NXS, int NWS, int XPP>
+__device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc,
+                                                 const unsigned (&xoff)[NXS], const unsigned (&woff)[NWS],
+                                                 unsigned xcoff, unsigned wcoff, char* ls, int wave_u) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+#pragma unroll
+  for (int i = 0; i < NXS; ++i) {
+    const unsigned vo = xoff[i] == OOB ? OOB : xoff[i] + xcoff;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(ls + (i * 256 + wave_u * 64) * 16), 16, vo, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    const unsigned vo = woff[i] == OOB ? OOB : woff[i] + wcoff;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(ls + (XPP + i * 256 + wave_u * 64) * 16), 16, vo, 0, 0, 0);
+  }
+}
+
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   typedef typename Frag<T>::type frag_t;
@@ -63,10 +82,15 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   constexpr int WP = NB * TAPS * 64 * PPO;
   constexpr int NXS = (XP + 255) / 256;
   constexpr int NWS = (WP + 255) / 256;
-  constexpr int STAGE = XP + WP;            // pieces per stage
+  constexpr int XPP = NXS * 256, WPP = NWS * 256;   // stage regions padded to whole wave instructions
+  constexpr int STAGE = XPP + WPP;          // 16-byte slots per ring stage
+  constexpr int NSTG = sizeof(T) == 2 ? 3 : 2;   // ring depth (fp32 tiles are twice as large)
+  constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
+  constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
+  static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
 
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
-  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
+  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];   // NSTG ring stages
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,18 +111,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
   const T* wb = reinterpret_cast<const T*>(p.w);
 
-  // ---- per-thread staging plan (independent of the chunk) ----
-  // Activation pieces come through a buffer descriptor over this image's view: an
-  // out-of-image pixel (zero padding) gets an offset beyond the descriptor's range and the
-  // hardware returns zeros, as it does for the second octet of the last chunk when the
-  // channel count is not a multiple of 16.  No load is ever conditional, so the loads of
-  // chunk c+1 stay in flight behind the MFMAs of chunk c.
+  // ---- staging plan: LDS-DMA ring ----
+  // Every chunk (16 input channels: the halo tile of two octet planes + the 9-tap weight block)
+  // goes global -> LDS by buffer_load ... lds, 16 bytes per lane, into one of NSTG ring stages;
+  // nothing passes through VGPRs.  Threads own consecutive 16-byte slots (the LDS image of a wave
+  // instruction is lane-linear); the per-lane SOURCE offset carries the layout.  An out-of-image
+  // pixel (zero padding), the second octet of the last chunk when Cin % 16 != 0, and the pad
+  // slots get an out-of-range offset, for which the hardware deposits zeros in LDS.  No load is
+  // conditional, so each wave issues exactly DMA_PER_CHUNK instructions per chunk and a counted
+  // s_waitcnt vmcnt() retires exactly one chunk while the next stays in flight across the barrier.
   constexpr unsigned OOB = 0xFFFFFFF0u;
   const unsigned plane_bytes = (unsigned)(plane_in * sizeof(T));
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(xb), 0, (int)((unsigned)p.cin8 * plane_bytes), 0x00020000);
-  unsigned xoff[NXS];
-  unsigned xok = 0;
+  const unsigned wchunk_bytes = TAPS * 512 * sizeof(T);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(wb + (long)nb0 * p.nchunk * (TAPS * 512)), 0,
+      (int)((unsigned)NB * p.nchunk * wchunk_bytes), 0x00020000);
+  unsigned xoff[NXS], woff[NWS];
 #pragma unroll
   for (int i = 0; i < NXS; ++i) {
     int piece = tid + i * 256;
@@ -108,46 +138,22 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     int r = pix / IW, c = pix % IW;
     int gy = iy0 + r, gx = ix0 + c;
     bool ok = piece < XP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    xoff[i] = (unsigned)h * plane_bytes + (unsigned)(((gy * p.W + gx) * 8 + q * EPP) * (int)sizeof(T));
-    if (ok) xok |= 1u << i;
+    // out-of-image slots stay out of range for every chunk: OOB minus the largest chunk offset
+    xoff[i] = ok ? (unsigned)h * plane_bytes + (unsigned)(((gy * p.W + gx) * 8 + q * EPP) * (int)sizeof(T))
+                 : OOB;
   }
-  int woff[NWS];
 #pragma unroll
   for (int i = 0; i < NWS; ++i) {
     int piece = tid + i * 256;
-    if (piece >= WP) piece = WP - 1;
     int nb = piece / (TAPS * 64 * PPO);
     int rem = piece % (TAPS * 64 * PPO);
-    woff[i] = (nb0 + nb) * p.nchunk * (TAPS * 512) + rem * EPP;
+    woff[i] = piece < WP ? (unsigned)nb * p.nchunk * wchunk_bytes + (unsigned)rem * 16u : OOB;
   }
-
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  u32x4 xr[NXS], wr[NWS];
-  auto load_regs = [&](int chunk) {
-    const unsigned coff = (unsigned)chunk * 2u * plane_bytes;
-#pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      unsigned vo = ((xok >> i) & 1) ? xoff[i] + coff : OOB;
-      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0);
-      xr[i] = v;
-    }
-    const T* wc = wb + (long)chunk * (TAPS * 512);
-#pragma unroll
-    for (int i = 0; i < NWS; ++i) wr[i] = *reinterpret_cast<const u32x4*>(wc + woff[i]);
-  };
-  auto store_lds = [&](int stage) {
-    u32x4* sx = smem + stage * STAGE;
-    u32x4* sw = sx + XP;
-#pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      int piece = tid + i * 256;
-      if (piece < XP) sx[piece] = xr[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NWS; ++i) {
-      int piece = tid + i * 256;
-      if (piece < WP) sw[piece] = wr[i];
-    }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int chunk, int stage) {
+    conv_issue_chunk<T, NXS, NWS, XPP>(xrsrc, wrsrc, xoff, woff, (unsigned)chunk * 2u * plane_bytes,
+                                       (unsigned)chunk * wchunk_bytes,
+                                       reinterpret_cast<char*>(smem + stage * STAGE), wave_u);
   };
 
   f32x16 acc[RW][NB];
@@ -167,15 +173,20 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
   }
 
-  load_regs(0);
-  store_lds(0);
-  __syncthreads();
-
+#pragma unroll
+  for (int j = 0; j < DIST; ++j)
+    if (j < p.nchunk) issue(j, j);
+  int stage = 0;
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    const int stage = chunk & 1;
-    if (chunk + 1 < p.nchunk) load_regs(chunk + 1);
+    // this chunk's DMA has landed (the DIST-1 younger chunks may stay in flight) ...
+    if (DIST > 1 && chunk + DIST - 1 < p.nchunk)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * DMA_PER_CHUNK) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // ... in every wave; and every wave is done with the previous stage
+    if (chunk + DIST < p.nchunk) issue(chunk + DIST, stage == 0 ? NSTG - 1 : stage - 1);
     const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
-    const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XP);
+    const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = tap / KS, dx = tap % KS;
@@ -189,8 +200,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         for (int n = 0; n < NB; ++n) mma(wf[n], xf, acc[rg][n]);
       }
     }
-    if (chunk + 1 < p.nchunk) store_lds(stage ^ 1);
-    __syncthreads();
+    stage = stage == NSTG - 1 ? 0 : stage + 1;
   }
 
   // ---- epilogue ----
@@ -267,8 +277,8 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
   constexpr int TH = 4 * RW * (32 >> LTW);
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
   constexpr int PPO = Oct<T>::PPO;
-  constexpr int STAGE = 2 * IH * IW * PPO + NB * KS * KS * 64 * PPO;
-  constexpr int LDS = 2 * STAGE * 16;
+  constexpr int XPP = ((2 * IH * IW * PPO + 255) / 256) * 256, WPP = ((NB * KS * KS * 64 * PPO + 255) / 256) * 256;
+  constexpr int LDS = (sizeof(T) == 2 ? 3 : 2) * (XPP + WPP) * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvParams p = p0;
   p.tiles_x = (p.OW + TW - 1) / TW;
