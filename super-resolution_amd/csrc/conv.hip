@@ -187,18 +187,31 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     if (chunk + DIST < p.nchunk) issue(chunk + DIST, stage == 0 ? NSTG - 1 : stage - 1);
     const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
     const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
+    // Fragment reads run one tap ROW (KS taps) ahead of the MFMAs that consume them: with one
+    // wave per SIMD nothing else hides the LDS latency.
+    frag_t wf[2][KS][NB], xf[2][KS][RW];
+    auto read_row = [&](int dy, int buf) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = tap / KS, dx = tap % KS;
-      frag_t wf[NB];
+      for (int dx = 0; dx < KS; ++dx) {
+        const int tap = dy * KS + dx;
 #pragma unroll
-      for (int n = 0; n < NB; ++n) wf[n] = sw[((n * TAPS + tap) * 2 + hh) * 32 + pl];
+        for (int n = 0; n < NB; ++n) wf[buf][dx][n] = sw[((n * TAPS + tap) * 2 + hh) * 32 + pl];
 #pragma unroll
-      for (int rg = 0; rg < RW; ++rg) {
-        frag_t xf = sx[xslot[rg] + dy * IW + dx];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) mma(wf[n], xf, acc[rg][n]);
+        for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
       }
+    };
+    read_row(0, 0);
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      if (dy + 1 < KS) read_row(dy + 1, (dy + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     stage = stage == NSTG - 1 ? 0 : stage + 1;
   }
