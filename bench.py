@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--wgrad-overlap", type=int, default=1, help="weight gradients on a side stream (0/1)")
+    ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,12 +112,16 @@ def main():
     import ctypes
     G = importlib.import_module("super-resolution_amd.esrgan.generator")
     T = importlib.import_module("super-resolution_amd.train")
+    E = importlib.import_module("super-resolution_amd.engine")
     D = importlib.import_module("super-resolution_amd.parallel")
 
     torch.manual_seed(0)
     gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
     B, h = args.batch, args.patch
     sync = D.FlatGradAllReduce(world) if world > 1 else None
+    E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
+    if args.wgrad_rdbs is not None:
+        E.GeneratorPlan.trunk_wgrad_rdbs = args.wgrad_rdbs
     trainer = T.GeneratorWarmupTrainer(gen, (B, 3, h, h), torch.bfloat16, grad_sync=sync, n_streams=args.streams)
     gcpu = torch.Generator().manual_seed(1234 + rank)
     lr = (torch.rand((B, 3, h, h), generator=gcpu) * 2 - 1).to(dev)

@@ -8,8 +8,8 @@
 // every LDS fragment read is one 16-byte slot per lane.
 //
 // One workgroup = 4 waves = (4*RW) groups of 32 output pixels x (32*NB) couts.
-// K loop over 16-channel chunks through a 2- or 3-stage LDS ring filled by LDS-DMA
-// (buffer_load ... lds): later chunks stream in while chunk c is multiplied; one
+// K loop over 16-channel chunks through a 3-stage LDS ring filled by LDS-DMA
+// (buffer_load ... lds): chunk c+2 streams in while chunk c is multiplied; one
 // counted s_waitcnt vmcnt + one raw s_barrier per chunk.
 //
 // Epilogue (bias, derivative mask, LeakyReLU/ReLU, residual scaling, optional
@@ -66,13 +66,6 @@ __device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, _
 }
 
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
-struct RingDepth {
-  // fp32 tiles are twice as large; the two-block and four-row-group tiles stay at two stages so
-  // that two workgroups (or one plus a weight-gradient workgroup) still fit a CU's 160 KB
-  static constexpr int value = (sizeof(T) == 2 && NB == 1 && RW <= 2) ? 3 : 2;
-};
-
-template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   typedef typename Frag<T>::type frag_t;
   constexpr int TW = 1 << LTW;
@@ -91,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   constexpr int NWS = (WP + 255) / 256;
   constexpr int XPP = NXS * 256, WPP = NWS * 256;   // stage regions padded to whole wave instructions
   constexpr int STAGE = XPP + WPP;          // 16-byte slots per ring stage
-  constexpr int NSTG = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value;   // ring depth
+  constexpr int NSTG = sizeof(T) == 2 ? 3 : 2;   // ring depth (fp32 tiles are twice as large)
   constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
   constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
   static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
@@ -99,9 +92,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
   extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];   // NSTG ring stages
 
-  // Convolutions sit on the critical path of a layer chain; weight-gradient workgroups that
-  // share the CU (other stream) only fill the issue slots these waves leave idle.
-  __builtin_amdgcn_s_setprio(3);
+#ifdef DBG_EMPTY
+  if (p.H > 0) return;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -183,6 +176,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
   }
 
+#ifdef DBG_NOLOOP
+  if (p.H < 0) {
+#endif
 #pragma unroll
   for (int j = 0; j < DIST; ++j)
     if (j < p.nchunk) issue(j, j);
@@ -194,7 +190,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // ... in every wave; and every wave is done with the previous stage
+#ifndef DBG_NODMA
     if (chunk + DIST < p.nchunk) issue(chunk + DIST, stage == 0 ? NSTG - 1 : stage - 1);
+#endif
     const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
     const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
     // Fragment reads run one tap ROW (KS taps) ahead of the MFMAs that consume them: with one
@@ -210,6 +208,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
       }
     };
+#ifndef DBG_NOMMA
     read_row(0, 0);
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
@@ -220,13 +219,26 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg)
 #pragma unroll
-          for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
+          for (int n = 0; n < NB; ++n) {
+#ifdef DBG_NOLDSREAD
+            mma(wf[0][0][0], xf[0][0][0], acc[rg][n]);
+#else
+            mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
+#endif
+          }
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     stage = stage == NSTG - 1 ? 0 : stage + 1;
   }
 
   // ---- epilogue ----
+#ifdef DBG_NOEPI
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
+#ifdef DBG_NOLOOP
+  }
+#endif
   const long plane_out = (long)p.OH * p.OW * 8;
 #pragma unroll
   for (int rg = 0; rg < RW; ++rg) {
@@ -301,7 +313,7 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
   constexpr int PPO = Oct<T>::PPO;
   constexpr int XPP = ((2 * IH * IW * PPO + 255) / 256) * 256, WPP = ((NB * KS * KS * 64 * PPO + 255) / 256) * 256;
-  constexpr int LDS = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value * (XPP + WPP) * 16;
+  constexpr int LDS = (sizeof(T) == 2 ? 3 : 2) * (XPP + WPP) * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvParams p = p0;
   p.tiles_x = (p.OW + TW - 1) / TW;

@@ -356,10 +356,64 @@ class Plan:
     def freeze(ops: list):
         return (L.Op * len(ops))(*ops) if ops else None
 
-    def run(self, frozen) -> None:
+    def run(self, frozen, stream: Optional[torch.cuda.Stream] = None) -> None:
         if frozen is None:
             return
-        L.check(self.lib.srx_run_ops(C.addressof(frozen), len(frozen), stream_ptr(self.device)), "srx_run_ops")
+        sp = stream.cuda_stream if stream is not None else stream_ptr(self.device)
+        L.check(self.lib.srx_run_ops(C.addressof(frozen), len(frozen), sp), "srx_run_ops")
+
+    # ------------------------------------------------- two-stream op lists
+    # Weight-gradient launches depend only on tensors the data-gradient chain has already
+    # produced, and nothing in that chain waits for them.  A split op list keeps the chain on the
+    # caller's stream and moves each weight-gradient launch to a side stream behind an event, so
+    # its workgroups share the CUs with the chain's (one wave per SIMD each) and fill the MFMA
+    # issue slots the chain's short launches leave idle.
+    @staticmethod
+    def split_ops(main: "OpList", side_marks: List[Tuple[int, "OpList"]]):
+        """main: ops of the chain; side_marks: (number of chain ops that must precede, ops).
+        Returns (segments, serial ops, serial meta): segments = [(chain ops, side ops|None)],
+        the serial list interleaves both in dependency order for one-stream profiling."""
+        segs, serial, meta = [], [], []
+        pos = 0
+        for after, ops in side_marks:
+            if after > pos or not segs:
+                chunk = main[pos:after]
+                segs.append([list(chunk), list(ops)])
+                serial += chunk
+                meta += main.meta[pos:after]
+                pos = after
+            else:
+                segs[-1][1] += list(ops)
+            serial += ops
+            meta += ops.meta
+        if pos < len(main) or not segs:
+            segs.append([list(main[pos:]), []])
+            serial += main[pos:]
+            meta += main.meta[pos:]
+        frozen = [(Plan.freeze(a), Plan.freeze(b)) for a, b in segs]
+        return frozen, Plan.freeze(serial), meta
+
+    def run_split(self, segments) -> None:
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_events = []
+            self._side_done = torch.cuda.Event()
+        side = self._side_stream
+        used = False
+        for i, (chain, aside) in enumerate(segments):
+            self.run(chain)
+            if aside is not None:
+                if i >= len(self._side_events):
+                    self._side_events.append(torch.cuda.Event())
+                ev = self._side_events[i]
+                ev.record(main)
+                side.wait_event(ev)
+                self.run(aside, stream=side)
+                used = True
+        if used:
+            self._side_done.record(side)
+            main.wait_event(self._side_done)
 
     # ----------------------------------------------------- layout helpers
     def nchw_to_c8(self, src: torch.Tensor, dst: View):
@@ -502,8 +556,16 @@ class _GenBase(Plan):
             self.wgrad(ops, (cur, 0), (G, 0), tasks, B, h, w)
 
     # ---- shared run API ---------------------------------------------------
+    bwd_segments = None     # two-stream form of bwd_ops (Plan.split_ops), when the plan built one
+
+    def run_backward_ops(self) -> None:
+        if self.bwd_segments is not None:
+            self.run_split(self.bwd_segments)
+        else:
+            self.run(self.bwd_ops)
+
     def backward_c8(self) -> None:
-        self.run(self.bwd_ops)
+        self.run_backward_ops()
         self.run_unpack()
 
 
@@ -515,6 +577,8 @@ class GeneratorPlan(_GenBase):
     """
 
     trunk_wgrad_slices = 4
+    overlap_wgrad = True        # weight gradients on a side stream, beside the data-gradient chain
+    trunk_wgrad_rdbs = 6        # dense blocks per weight-gradient launch in that mode (0: all in one)
 
     def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
                  *, in_ch=3, out_ch=3, nf=64, gc=32, num_blocks=23, need_grad=True,
@@ -593,50 +657,80 @@ class GeneratorPlan(_GenBase):
         self.gfeat = self.buf(B, nf, h, w)
         self.gX0 = self.buf(B, in_ch, h, w) if self.need_input_grad else None
 
+        side_marks: List[Tuple[int, OpList]] = []
+
+        def aside(emit):
+            """Record a weight-gradient launch that may start once every chain op recorded so
+            far has run."""
+            if self.overlap_wgrad:
+                ops = OpList()
+                emit(ops)
+                side_marks.append((len(bwd), ops))
+            else:
+                emit(bwd)
+
         # conv_last: GY -> gV, masked by LeakyReLU'(V)               (esrgan/generator.py:71)
-        self.layer_wgrad(bwd, P, "conv_last", (self.V, 0), (self.GY, 0), B, H4, W4)
+        aside(lambda o: self.layer_wgrad(o, P, "conv_last", (self.V, 0), (self.GY, 0), B, H4, W4))
         self.conv(bwd, (self.GY, 0), (self.gV, 0), self.dgrad_layer(P, "conv_last", nf), 0, B, H4, W4,
                   out_ch, nf, mask=(self.V, 0), mask_slope=LRELU)
         # conv_hr: gV -> gU1, masked by LeakyReLU'(U1) (activation of upsample.1, :48)
-        self.layer_wgrad(bwd, P, "conv_hr", (self.U1, 0), (self.gV, 0), B, H4, W4)
+        aside(lambda o: self.layer_wgrad(o, P, "conv_hr", (self.U1, 0), (self.gV, 0), B, H4, W4))
         self.conv(bwd, (self.gV, 0), (self.gU1, 0), self.dgrad_layer(P, "conv_hr", nf), 0, B, H4, W4,
                   nf, nf, mask=(self.U1, 0), mask_slope=LRELU)
         # upsample.1: inverse shuffle, then conv backward, masked by LeakyReLU'(U0)
         self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU1, 0), c=(self.gyu1, 0), B=B, C_=nf, H=2 * h, W=2 * w)
-        self.layer_wgrad(bwd, P, "upsample.1.conv", (self.U0, 0), (self.gyu1, 0), B, 2 * h, 2 * w)
+        aside(lambda o: self.layer_wgrad(o, P, "upsample.1.conv", (self.U0, 0), (self.gyu1, 0), B, 2 * h, 2 * w))
         self.conv(bwd, (self.gyu1, 0), (self.gU0, 0), self.dgrad_layer(P, "upsample.1.conv", nf), 0, B,
                   2 * h, 2 * w, 4 * nf, nf, mask=(self.U0, 0), mask_slope=LRELU)
         # upsample.0 (its input T1 = feat + trunk has no activation)
         self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU0, 0), c=(self.gyu0, 0), B=B, C_=nf, H=h, W=w)
-        self.layer_wgrad(bwd, P, "upsample.0.conv", (self.T1, 0), (self.gyu0, 0), B, h, w)
+        aside(lambda o: self.layer_wgrad(o, P, "upsample.0.conv", (self.T1, 0), (self.gyu0, 0), B, h, w))
         self.conv(bwd, (self.gyu0, 0), (self.gT1, 0), self.dgrad_layer(P, "upsample.0.conv", nf), 0, B, h, w,
                   4 * nf, nf)
         # conv_body: gT1 -> gradient of the last RRDB's output
-        self.layer_wgrad(bwd, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w)
+        aside(lambda o: self.layer_wgrad(o, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w))
         last_dst = (self.G[nR - 1], g8) if nR else (self.gfeat, 0)
         self.conv(bwd, (self.gT1, 0), last_dst, self.dgrad_layer(P, "conv_body", nf), 0, B, h, w, nf, nf)
-        trunk_tasks: list = []
+
+        # Dense blocks, last to first.  Their weight gradients go out in launches of several
+        # blocks each: long-running workgroups, few pixel slices (little atomic traffic), block
+        # order keeps one block's buffers hot in L2.
+        per_launch = self.trunk_wgrad_rdbs if (self.overlap_wgrad and self.trunk_wgrad_rdbs > 0) else nR
+        pending: list = []
+        n_pending = 0
+
+        def flush():
+            nonlocal pending, n_pending
+            if not pending:
+                return
+            tasks, nblocks = pending, n_pending
+            pending, n_pending = [], 0
+            per_block = len(tasks) // nblocks
+            aside(lambda o: self.wgrad(o, None, None, tasks, B, h, w, nslices=self.trunk_wgrad_slices,
+                                       x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
+                                       group=per_block if per_block * nblocks == len(tasks) else 0))
+
         for r in range(nR - 1, -1, -1):
             blk, q = divmod(r, 3)
             dst = (self.G[r - 1], g8) if r > 0 else (self.gfeat, 0)
             self.emit_rdb_bwd(bwd, P, f"body.{blk}.rdb{q + 1}.", Rb(r), self.G[r], dst, B, h, w, nf, gc, q,
-                              (self.G[r + 2], g8) if q == 0 else None, defer_wgrad=trunk_tasks)
-        if trunk_tasks:
-            # every dense block's weight gradients in ONE launch: long-running workgroups, few
-            # pixel slices (little atomic traffic), block order keeps one block's buffers hot
-            per_block = len(trunk_tasks) // nR
-            self.wgrad(bwd, None, None, trunk_tasks, B, h, w, nslices=self.trunk_wgrad_slices,
-                       x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
-                       group=per_block if per_block * nR == len(trunk_tasks) else 0)
+                              (self.G[r + 2], g8) if q == 0 else None, defer_wgrad=pending)
+            n_pending += 1
+            if n_pending == per_launch:
+                flush()
+        flush()
         # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
         self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
                      n=self.gfeat.t.numel())
-        self.layer_wgrad(bwd, P, "conv_first", (self.X0, 0), (self.gfeat, 0), B, h, w)
+        aside(lambda o: self.layer_wgrad(o, P, "conv_first", (self.X0, 0), (self.gfeat, 0), B, h, w))
         if self.need_input_grad:
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
-        self.bwd_ops = self.freeze(bwd)
-        self.bwd_meta = bwd.meta
+        if self.overlap_wgrad:
+            self.bwd_segments, self.bwd_ops, self.bwd_meta = self.split_ops(bwd, side_marks)
+        else:
+            self.bwd_ops = self.freeze(bwd)
+            self.bwd_meta = bwd.meta
 
     # ------------------------------------------------------------------ API
     def forward_c8(self, x_nchw: torch.Tensor) -> Buf:

@@ -78,7 +78,7 @@ class GeneratorWarmupTrainer:
         L.check(p.lib.srx_l1_c8_nchw(p.dt, Y.ptr(), Y.img_stride, hr_img.data_ptr(), self.loss_acc.data_ptr(),
                                      p.GY.ptr(), p.GY.img_stride, 1.0 / self.n_streams, Y.B, p.out_ch, Y.H, Y.W,
                                      engine.stream_ptr(p.device)), "srx_l1_c8_nchw")
-        p.run(p.bwd_ops)
+        p.run_backward_ops()
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
         hr_img = hr_img.contiguous()
