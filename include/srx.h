@@ -197,7 +197,8 @@ int srx_gap_bwd(int dtype, const void* gy, void* gx, int64_t gx_img_stride,
  * nn.LeakyReLU(0.2) / ReLU given the activation's OUTPUT (esrgan/generator.py:15,45,63). */
 int srx_act_bwd(int dtype, const void* g, const void* act_out, void* out, float slope, int64_t n,
                 void* stream);
-/* y = a*x + b*y over n elements of dtype (RRDB skip add, esrgan/generator.py:37). */
+/* y = a*x + b*y over n elements of dtype, any n > 0, 16-byte aligned pointers (RRDB skip
+ * add, esrgan/generator.py:37; sums of gradient buffers). */
 int srx_axpby(int dtype, const void* x, void* y, float a, float b, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ losses */

@@ -272,8 +272,9 @@ class DiscriminatorPlan(ChainPlan):
             out += [n + ".bias", n + ".weight_orig"]
         return out
 
-    def forward_logits(self, x_nchw: Optional[torch.Tensor], training: bool) -> torch.Tensor:
-        """Power iteration (training) -> sigma -> pack W/sigma -> convolutions.  Returns [B,1] fp32."""
+    def forward_buf(self, x_nchw: Optional[torch.Tensor], training: bool) -> Buf:
+        """Power iteration (training) -> sigma -> pack W/sigma -> convolutions.  x_nchw None: the
+        input is already in A[0].  Returns the logits buffer (one C8 image of width B, slot 0)."""
         L.check(self.lib.srx_sn_power_iter(self._sn_dev.data_ptr(), self.nl, 1 if training else 0,
                                            self.max_rows, self.max_cols, stream_ptr(self.device)),
                 "srx_sn_power_iter")
@@ -282,8 +283,11 @@ class DiscriminatorPlan(ChainPlan):
         if self.need_param_grad:
             torch._foreach_copy_(self._u, self._mod_u)
             torch._foreach_copy_(self._v, self._mod_v)
-        out = self.forward_c8(x_nchw)
-        return out.t.view(self.B, 8)[:, 0:1].float()
+        return self.forward_c8(x_nchw)
+
+    def forward_logits(self, x_nchw: Optional[torch.Tensor], training: bool) -> torch.Tensor:
+        """forward_buf, returned as a [B,1] fp32 tensor."""
+        return self.forward_buf(x_nchw, training).t.view(self.B, 8)[:, 0:1].float()
 
     def set_output_grad(self, g_logits: torch.Tensor) -> None:
         g = self.gA[-1].t

@@ -319,8 +319,14 @@ __global__ void gap_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, lon
 }
 
 template <typename T>
-__global__ void axpby_kernel(const T* __restrict__ x, T* __restrict__ y, float a, float bb, long nocts) {
+__global__ void axpby_kernel(const T* __restrict__ x, T* __restrict__ y, float a, float bb, long n) {
+  const long nocts = (n + 7) / 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nocts; i += (long)gridDim.x * blockDim.x) {
+    if (i * 8 + 8 > n) {   // ragged tail: element by element
+      for (long e = i * 8; e < n; ++e)
+        y[e] = (T)(a * (float)x[e] + (bb != 0.f ? bb * (float)y[e] : 0.f));
+      continue;
+    }
     float u[8], v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     load_oct(x + i * 8, u);
     if (bb != 0.f) load_oct(y + i * 8, v);
@@ -640,10 +646,11 @@ int srx_gap_bwd(int dtype, const void* gy, void* gx, int64_t gx_is, const void* 
 }
 
 int srx_axpby(int dtype, const void* x, void* y, float a, float b, int64_t n, void* stream) {
-  SRX_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "srx_axpby: n must be a positive multiple of 8");
+  SRX_CHECK_ARG(x && y && n > 0, "srx_axpby: null pointer or n <= 0");
+  SRX_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "srx_axpby: x and y must be 16-byte aligned");
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(axpby_kernel<bf16>, dim3(grid_for(n / 8)), dim3(TPB), 0, STREAM, (const bf16*)x, (bf16*)y, a, b, (long)(n / 8)),
-             hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(n / 8)), dim3(TPB), 0, STREAM, (const float*)x, (float*)y, a, b, (long)(n / 8)));
+             hipLaunchKernelGGL(axpby_kernel<bf16>, dim3(grid_for((n + 7) / 8)), dim3(TPB), 0, STREAM, (const bf16*)x, (bf16*)y, a, b, (long)n),
+             hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for((n + 7) / 8)), dim3(TPB), 0, STREAM, (const float*)x, (float*)y, a, b, (long)n));
   return srx_check_launch("axpby");
 }
 

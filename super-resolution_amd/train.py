@@ -9,13 +9,20 @@ the caller reads whenever it wants to log.
 """
 from __future__ import annotations
 
-from typing import Optional
+import math
+from typing import Callable, Dict, Optional
 
 import torch
 
 from . import _lib as L
-from . import engine
+from . import chain, engine
 from .utils.flat import flatten_parameters
+
+
+def cosine_lr(base_lr: float, epoch: int, t_max: int = 1000, eta_min: float = 1e-7) -> float:
+    """Closed form of ``CosineAnnealingLR(T_max, eta_min)`` after ``epoch`` scheduler steps
+    (esrgan/train_esrgan.py:159-160,188)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max)) / 2.0
 
 
 class FlatAdam:
@@ -116,3 +123,130 @@ class GeneratorWarmupTrainer:
         self.loss_acc.zero_()
         self.steps = 0
         return v
+
+
+class AdversarialTrainer:
+    """One discriminator step + one generator step per call, the body of the reference's
+    ``train_one_epoch`` (esrgan/train_esrgan.py:87-111), entirely in libsrx:
+
+      fake = G(lr)
+      D step : loss_disc = (BCE(D(hr),1) + BCE(D(fake),0)) / 2  -> Adam on D       (:88-98)
+      G step : loss_gen = l_l1*L1(fake,hr) + l_adv*BCE(D(fake),1) + l_percep*VGG(fake,hr)
+               -> Adam on G                                                          (:102-111)
+
+    As in the reference the discriminator runs three training-mode forwards per step, so
+    every spectral-norm layer's u, v advance three power iterations, and the G step sees the
+    discriminator weights after their update.  The G step computes no discriminator weight
+    gradients (the reference discards them at the next ``disc.zero_grad``, :95).  bf16 needs
+    no loss scaling, so there is no GradScaler.  Losses accumulate on the device;
+    ``losses()`` is the only host synchronisation.
+
+    grad_sync_d / grad_sync_g (optional) are called with the flat gradient buffer before the
+    respective optimizer step (data-parallel all-reduce hooks)."""
+
+    def __init__(self, gen, disc, vgg_loss, batch_shape, compute_dtype=torch.bfloat16, lr: float = 2e-4,
+                 lambda_l1: float = 1.0, lambda_adv: float = 5e-3, lambda_percep: float = 1.0,
+                 grad_sync_g: Optional[Callable] = None, grad_sync_d: Optional[Callable] = None):
+        B, _, h, w = batch_shape
+        H, W = 4 * h, 4 * w
+        self.gen, self.disc, self.vgg_loss = gen, disc, vgg_loss
+        self.lams = (lambda_l1, lambda_adv, lambda_percep)
+        self.flat_g = flatten_parameters(gen)
+        self.flat_d = flatten_parameters(disc)
+        dev = self.flat_g.device
+        self.device = dev
+        gparams = {n: p.data for n, p in gen.named_parameters()}
+        self.gplan = engine.GeneratorPlan(
+            gparams, B, h, w, compute_dtype, in_ch=gen.conv_first.in_channels,
+            out_ch=gen.conv_last.out_channels, nf=gen.conv_first.out_channels,
+            gc=gen.body[0].rdb1.conv1.out_channels if len(gen.body) else 32, num_blocks=len(gen.body),
+            need_grad=True, need_input_grad=False)
+        dparams = {n: p.data for n, p in disc.named_parameters()}
+        dbufs = {n: b for n, b in disc.named_buffers()}
+        mk = lambda pg, ig: chain.DiscriminatorPlan(dparams, dbufs, B, H, W, compute_dtype,
+                                                    need_param_grad=pg, need_input_grad=ig)
+        self.d_real, self.d_fake, self.d_gen = mk(True, False), mk(True, False), mk(False, True)
+        vparams = {n: (p.data if p.dtype == torch.float32 else p.data.float())
+                   for n, p in vgg_loss.vgg.named_parameters()}
+        self._vparams = vparams
+        self.v_fake = chain.VGGFeaturePlan(vparams, B, H, W, compute_dtype, need_input_grad=True)
+        self.v_real = chain.VGGFeaturePlan(vparams, B, H, W, compute_dtype, need_input_grad=False)
+        self.v_fake.run_packing()
+        self.v_real.run_packing()                 # frozen weights: packed once
+        self.opt_g = FlatAdam(self.flat_g, lr=lr)
+        self.opt_d = FlatAdam(self.flat_d, lr=lr)
+        self.acc = torch.zeros(4, dtype=torch.float32, device=dev)   # loss_disc, adv, l1, vgg
+        self.grad_sync_g, self.grad_sync_d = grad_sync_g, grad_sync_d
+        self.steps = 0
+        self.B = B
+
+    def set_lr(self, lr: float) -> None:
+        self.opt_g.lr = lr
+        self.opt_d.lr = lr
+
+    def _acc_ptr(self, i: int) -> int:
+        return self.acc.data_ptr() + 4 * i
+
+    def _d_pass(self, plan, x_nchw, fake_c8, target: float) -> None:
+        lib, sp = plan.lib, engine.stream_ptr(self.device)
+        if fake_c8 is not None:
+            plan.A[0].t.copy_(fake_c8.t)           # fake.detach(): the same values, no graph
+        out = plan.forward_buf(x_nchw, training=True)
+        L.check(lib.srx_bce_logits(plan.dt, out.ptr(), self.B, target, 0.5, self._acc_ptr(0),
+                                   plan.gA[-1].ptr(), 1.0, sp), "srx_bce_logits")
+        plan.backward_c8()
+
+    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
+        lr_img, hr_img = lr_img.contiguous(), hr_img.contiguous()
+        gp, lib = self.gplan, self.gplan.lib
+        sp = engine.stream_ptr(self.device)
+        l_l1, l_adv, l_percep = self.lams
+        Y = gp.forward_c8(lr_img)
+        # ---- discriminator step (esrgan/train_esrgan.py:89-98)
+        self._d_pass(self.d_real, hr_img, None, 1.0)
+        self._d_pass(self.d_fake, None, Y, 0.0)
+        gd = self.d_real.flat_grad
+        L.check(lib.srx_axpby(L.F32, self.d_fake.flat_grad.data_ptr(), gd.data_ptr(), 1.0, 1.0, gd.numel(), sp),
+                "srx_axpby")
+        if self.grad_sync_d is not None:
+            self.grad_sync_d(gd)
+        self.opt_d.step(gd)
+        # ---- generator step (:102-111)
+        dg = self.d_gen
+        dg.A[0].t.copy_(Y.t)
+        out = dg.forward_buf(None, training=True)
+        L.check(lib.srx_bce_logits(dg.dt, out.ptr(), self.B, 1.0, 1.0, self._acc_ptr(1), dg.gA[-1].ptr(),
+                                   l_adv, sp), "srx_bce_logits")
+        dg.backward_c8()
+        vf, vr = self.v_fake, self.v_real
+        vf.A[0].t.copy_(Y.t)
+        fa = vf.forward_c8(None, pack=False)
+        fb = vr.forward_c8(hr_img, pack=False)
+        Bf, Cf, Hf, Wf = vf.geo[-1]
+        g = vf.gA[-1]
+        L.check(lib.srx_l1_c8(vf.dt, fa.ptr(), fa.img_stride, fb.ptr(), fb.img_stride, self._acc_ptr(3),
+                              g.ptr(), g.img_stride, l_percep, 0.0, Bf, Cf, Hf, Wf, sp), "srx_l1_c8")
+        vf.backward_c8()
+        L.check(lib.srx_l1_c8_nchw(gp.dt, Y.ptr(), Y.img_stride, hr_img.data_ptr(), self._acc_ptr(2),
+                                   gp.GY.ptr(), gp.GY.img_stride, l_l1, Y.B, gp.out_ch, Y.H, Y.W, sp),
+                "srx_l1_c8_nchw")
+        n = gp.GY.t.numel()
+        for src in (dg.gA[0], vf.gA[0]):           # dL/dfake = sum of the three branches
+            L.check(lib.srx_axpby(gp.dt, src.ptr(), gp.GY.ptr(), 1.0, 1.0, n, sp), "srx_axpby")
+        gp.run_backward_ops()
+        gp.run_unpack()
+        gg = gp.flat_grad
+        if self.grad_sync_g is not None:
+            self.grad_sync_g(gg)
+        self.opt_g.step(gg)
+        self.steps += 1
+
+    def losses(self) -> Dict[str, float]:
+        """Mean losses since the last call, named as the reference logs them
+        (esrgan/train_esrgan.py:113-117).  One host synchronisation."""
+        a = (self.acc / max(self.steps, 1)).tolist()
+        self.acc.zero_()
+        self.steps = 0
+        l_l1, l_adv, l_percep = self.lams
+        return {"loss_disc": a[0], "gen_adv_loss": a[1], "gen_l1_loss": a[2], "gen_vgg_loss": a[3],
+                "loss_gen": l_l1 * a[2] + l_adv * a[1] + l_percep * a[3]}

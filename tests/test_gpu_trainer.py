@@ -1,0 +1,122 @@
+"""GPU parity of the native trainers (one D step + one G step in libsrx, flat Adam) against
+the reference-generated adversarial-step golden and against the drop-in modules driven by
+stock torch losses / torch.optim.Adam exactly as esrgan/train_esrgan.py:87-111 does."""
+import copy
+import math
+
+import pytest
+import torch
+
+from helpers import O, fill_module_, golden, pkg, rel_err
+from test_gpu_generator import _grads_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(num_blocks=2):
+    G = pkg("esrgan.generator")
+    D = pkg("esrgan.discriminator")
+    Lm = pkg("utils.loss")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=5).cuda()
+    d = fill_module_(D.Discriminator(), salt=6).cuda()
+    with pytest.warns(UserWarning):
+        vgg = Lm.VGGLoss(device="cuda")
+    vgg.vgg.load_state_dict(O.make_state_dict(O.vgg19_state_dict_spec(), salt=7, gain=1.4))
+    return g, d, vgg
+
+
+def test_native_adversarial_step_matches_reference_golden():
+    """lr = 0 keeps the discriminator weights unchanged between the D and the G step, which is
+    how the golden 'adv_step' was produced (no optimizer in it)."""
+    man, _ = golden()
+    case = man["cases"]["adv_step"]
+    T = pkg("train")
+    g, d, vgg = _models()
+    lr = O.hash_input("adv.lr", (2, 3, 16, 16)).cuda()
+    hr = O.hash_input("adv.hr", (2, 3, 64, 64)).cuda()
+    tr = T.AdversarialTrainer(g, d, vgg, (2, 3, 16, 16), torch.float32, lr=0.0)
+    tr.step(lr, hr)
+    got = tr.losses()
+    assert abs(got["loss_disc"] - case["loss_disc"]) < 1e-4
+    for k in ("gen_adv_loss", "gen_l1_loss", "gen_vgg_loss", "loss_gen"):
+        assert abs(got[k] - case[k]) / abs(case[k]) < 1e-3, (k, got[k], case[k])
+    for n, p in d.named_parameters():
+        p.grad = tr.d_real.grads[n]
+    bad = _grads_close(d, case["d_grads"], 3e-3)
+    assert not bad, bad[:5]
+    for n, p in g.named_parameters():
+        p.grad = tr.gplan.grads[n]
+    bad = _grads_close(g, case["g_grads"], 1e-2)
+    assert not bad, bad[:5]
+
+
+def _dropin_step(g, d, vgg, opt_g, opt_d, lr, hr):
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    fake = g(lr)
+    disc_real = d(hr)
+    disc_fake = d(fake.detach())
+    loss_disc = (bce(disc_real, torch.ones_like(disc_real)) + bce(disc_fake, torch.zeros_like(disc_fake))) / 2
+    d.zero_grad(set_to_none=True)
+    loss_disc.backward()
+    opt_d.step()
+    dfg = d(fake)
+    adv, pix, per = bce(dfg, torch.ones_like(dfg)), l1(fake, hr), vgg(fake, hr)
+    loss_gen = 1.0 * pix + 5e-3 * adv + 1.0 * per
+    g.zero_grad(set_to_none=True)
+    loss_gen.backward()
+    opt_g.step()
+    return {"loss_disc": float(loss_disc), "gen_adv_loss": float(adv), "gen_l1_loss": float(pix),
+            "gen_vgg_loss": float(per), "loss_gen": float(loss_gen)}
+
+
+def test_native_trainer_tracks_dropin_modules_with_torch_adam():
+    T = pkg("train")
+    g1, d1, vgg = _models()
+    g2, d2 = copy.deepcopy(g1), copy.deepcopy(d1)
+    for m in (g1, d1, vgg):
+        m.compute_dtype = torch.float32
+    opt_g = torch.optim.Adam(g1.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    opt_d = torch.optim.Adam(d1.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    tr = T.AdversarialTrainer(g2, d2, vgg, (2, 3, 16, 16), torch.float32, lr=2e-4)
+    for s in range(2):
+        lr = O.hash_input(f"trk.lr{s}", (2, 3, 16, 16)).cuda()
+        hr = O.hash_input(f"trk.hr{s}", (2, 3, 64, 64)).cuda()
+        ref = _dropin_step(g1, d1, vgg, opt_g, opt_d, lr, hr)
+        tr.step(lr, hr)
+        got = tr.losses()
+        for k, v in ref.items():
+            assert abs(got[k] - v) / max(abs(v), 1e-6) < 2e-3, (s, k, got[k], v)
+    # parameters after two Adam steps: a step moves every weight by about lr, so compare in
+    # units of lr; near-zero gradients may legitimately flip their update's sign
+    for (n, p1), (_, p2) in zip(list(g1.named_parameters()) + list(d1.named_parameters()),
+                                list(g2.named_parameters()) + list(d2.named_parameters())):
+        diff = (p1.detach() - p2.detach()).abs() / 2e-4
+        assert float((diff > 0.2).float().mean()) < 0.01, n
+    # spectral-norm buffers advanced identically (six power iterations each)
+    for (n, b1), (_, b2) in zip(d1.named_buffers(), d2.named_buffers()):
+        assert rel_err(b2, b1) < 1e-3, n
+
+
+def test_native_trainer_bf16_runs_and_is_close_to_fp32():
+    T = pkg("train")
+    res = {}
+    for tdtype in (torch.float32, torch.bfloat16):
+        g, d, vgg = _models()
+        tr = T.AdversarialTrainer(g, d, vgg, (2, 3, 16, 16), tdtype, lr=1e-4)
+        for s in range(2):
+            tr.step(O.hash_input(f"bf.lr{s}", (2, 3, 16, 16)).cuda(), O.hash_input(f"bf.hr{s}", (2, 3, 64, 64)).cuda())
+        res[tdtype] = tr.losses()
+    for k, v in res[torch.float32].items():
+        assert math.isfinite(res[torch.bfloat16][k])
+        assert abs(res[torch.bfloat16][k] - v) / max(abs(v), 1e-6) < 5e-2, (k, res[torch.bfloat16][k], v)
+
+
+def test_cosine_lr_matches_torch_scheduler():
+    T = pkg("train")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=2e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=1000, eta_min=1e-7)
+    for epoch in range(1, 6):
+        opt.step()
+        sch.step()
+        assert abs(T.cosine_lr(2e-4, epoch) - opt.param_groups[0]["lr"]) < 1e-12
