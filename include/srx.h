@@ -37,7 +37,7 @@ int srx_version(void);
 const char* srx_last_error(void);
 /* sizeof() of the ABI structs, for binding self-checks: 0 srx_conv_desc, 1 srx_wgrad_task,
  * 2 srx_wgrad_desc, 3 srx_pack_seg, 4 srx_pack_layer, 5 srx_unpack_item, 6 srx_sn_layer,
- * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op; -1 for an unknown id. */
+ * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile; -1 for an unknown id. */
 int srx_sizeof(int which);
 
 /* ------------------------------------------------------------------ layout */
@@ -255,6 +255,31 @@ int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_p
  * fp32 parameter range: p,g,m,v of n elements; bias corrections from step. */
 int srx_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, float gscale, void* stream);
+
+/* -------------------------------------------------------- tiled inference */
+/* Tiling around the generator, reference inference.py:187-230 (_infer_tiled).
+ * A tile is a th x tw window of the reflect-padded LR image at (y0,x0); its 4x
+ * output lives at `offset` elements into a tile store, as one C8 octet plane
+ * [th*scale][tw*scale][8]. */
+typedef struct srx_tile {
+  int32_t y0, x0, th, tw;
+  int64_t offset;
+} srx_tile;
+/* F.pad(lr, [0,pad_w,0,pad_h], 'reflect') + the tile slices lr_padded[:, :, y:y+th, x:x+tw]
+ * (inference.py:199,218) for `count` equally sized tiles of ONE fp32 [C][h][w] image, written
+ * as a C8 batch [count][1][th][tw][8] (the generator's input layout).  tiles: DEVICE array
+ * of the `count` tiles to cut. */
+int srx_tile_gather(int dtype, const float* img, int C, int h, int w, const srx_tile* tiles /*DEVICE*/,
+                    int count, int th, int tw, void* dst, int64_t dst_img_stride, void* stream);
+/* The blend of inference.py:208-230 in gather form: for every pixel of the cropped output
+ * [C][OH][OW], sum over the covering tiles (row-major tile order, as the reference's loop)
+ * of tile_value*w and of w, w = window[ry]*window[rx]; out = sum/(wsum+1e-8), optionally
+ * clamped to [0,1] (inference.py:163); out_u8 (optional) = floor(clamp(v)*255) as
+ * to_pil_image does.  tiles: DEVICE [ny][nx] grid with tile (ky,kx) at LR origin
+ * (ky*stride, kx*stride); window: DEVICE fp32 [tile*scale]. */
+int srx_tile_blend(int dtype, const void* store, const srx_tile* tiles /*DEVICE*/, int ny, int nx,
+                   int stride, int tile, int scale, const float* window, float* out, uint8_t* out_u8,
+                   int C, int OH, int OW, int clamp01, void* stream);
 
 /* ------------------------------------------------------------ batched ops */
 #define SRX_OP_CONV 1

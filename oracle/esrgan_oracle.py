@@ -335,3 +335,54 @@ def make_state_dict(spec, salt: int = 0, dtype=torch.float32, gain: float = 1.0)
 def hash_input(name: str, shape, salt: int = 0) -> Tensor:
     """U(-1,1) synthetic image batch (value range of utils/datasets.py:38)."""
     return hash_uniform(name, shape, 1.0, salt)
+
+
+# ---------------------------------------------------------------------------
+# Tiled inference (reference inference.py:187-230, intended semantics)
+# ---------------------------------------------------------------------------
+def blend_window(n: int, kind: str = "hann") -> Tensor:
+    """1-D blending window of n samples.  "hann": torch.hann_window(n, periodic=False), what
+    inference.py:208-209 builds (zero at both ends).  "hann_pos": the interior n samples of an
+    (n+2)-point Hann window, strictly positive, so image borders and overlap-0 seams keep a
+    non-zero weight."""
+    if kind == "hann":
+        return torch.hann_window(n, periodic=False, dtype=torch.float32)
+    if kind == "hann_pos":
+        return torch.hann_window(n + 2, periodic=False, dtype=torch.float32)[1:-1].clone()
+    raise ValueError(kind)
+
+
+def tile_grid(h: int, w: int, tile: int, overlap: int):
+    """Padded size and tile origins of inference.py:191-199,214-217: returns
+    (ph, pw, [(y, x, th, tw)] in the reference's loop order)."""
+    stride = tile - overlap
+    pad_h = max(0, (stride - (h - tile) % stride) % stride)
+    pad_w = max(0, (stride - (w - tile) % stride) % stride)
+    ph, pw = h + pad_h, w + pad_w
+    tiles = []
+    for y in range(0, ph, stride):
+        for x in range(0, pw, stride):
+            tiles.append((y, x, min(y + tile, ph) - y, min(x + tile, pw) - x))
+    return ph, pw, tiles
+
+
+def infer_tiled(lr: Tensor, model_fn, tile: int, overlap: int, scale: int = 4,
+                window: str = "hann") -> Tensor:
+    """inference.py:187-230 with the window sliced on its spatial dims for clipped edge tiles
+    (the reference slices dims 0/1 of a 4-D tensor at :225-226, which cannot broadcast).
+    model_fn: [b,c,th,tw] -> [b,c,th*scale,tw*scale]."""
+    b, c, h, w = lr.shape
+    ph, pw, tiles = tile_grid(h, w, tile, overlap)
+    lr_padded = F.pad(lr, [0, pw - w, 0, ph - h], "reflect")
+    sr = torch.zeros((b, c, ph * scale, pw * scale), dtype=torch.float32)
+    wsum = torch.zeros_like(sr)
+    w1 = blend_window(tile * scale, window)
+    win = (w1.unsqueeze(1) * w1.unsqueeze(0)).expand(1, c, -1, -1)
+    for (y, x, th, tw) in tiles:
+        sr_tile = model_fn(lr_padded[:, :, y:y + th, x:x + tw]).float()
+        ys, xs = y * scale, x * scale
+        sh, sw = sr_tile.shape[2], sr_tile.shape[3]
+        sr[:, :, ys:ys + sh, xs:xs + sw] += sr_tile * win[:, :, :sh, :sw]
+        wsum[:, :, ys:ys + sh, xs:xs + sw] += win[:, :, :sh, :sw]
+    out = sr / (wsum + 1e-8)
+    return out[:, :, :h * scale, :w * scale]

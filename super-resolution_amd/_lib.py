@@ -82,6 +82,10 @@ class GenericArgs(C.Structure):
                 ("f0", f32), ("f1", f32), ("n", i64)]
 
 
+class Tile(C.Structure):
+    _fields_ = [("y0", i32), ("x0", i32), ("th", i32), ("tw", i32), ("offset", i64)]
+
+
 class _OpU(C.Union):
     _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs)]
 
@@ -121,6 +125,9 @@ _SIGS = {
     "srx_sn_backward": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "srx_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
     "srx_run_ops": (C.c_int, [vp, C.c_int, vp]),
+    "srx_tile_gather": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
+    "srx_tile_blend": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -142,7 +149,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         structs = (ConvDesc, WgradTask, WgradDesc, PackSeg, PackLayer, UnpackItem, SnLayer,
-                   SnBwdLayer, GenericArgs, Op)
+                   SnBwdLayer, GenericArgs, Op, Tile)
         for i, st in enumerate(structs):
             if l.srx_sizeof(i) != C.sizeof(st):
                 raise RuntimeError(f"libsrx ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in "

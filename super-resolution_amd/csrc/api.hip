@@ -32,6 +32,7 @@ int srx_sizeof(int which) {
     case 7: return (int)sizeof(srx_sn_bwd_layer);
     case 8: return (int)sizeof(srx_generic_args);
     case 9: return (int)sizeof(srx_op);
+    case 10: return (int)sizeof(srx_tile);
     default: return -1;
   }
 }
