@@ -29,12 +29,62 @@ class FlatAdam:
     """torch.optim.Adam(lr, betas=(0.9,0.999)) semantics (esrgan/train_esrgan.py:134-135)
     over flat fp32 parameter / gradient buffers: one srx_adam launch per step."""
 
-    def __init__(self, flat_param: torch.Tensor, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, flat_param: torch.Tensor, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 shapes=None):
         self.p = flat_param
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
+        # per-parameter shapes in parameters() order: what state_dict() needs to speak
+        # torch.optim.Adam's format (which indexes parameters by position)
+        self.shapes = [tuple(s) for s in shapes] if shapes is not None else [(flat_param.numel(),)]
+        assert sum(math.prod(s) for s in self.shapes) == flat_param.numel()
+
+    def state_dict(self) -> dict:
+        """The ``torch.optim.Adam.state_dict()`` layout the reference checkpoints hold
+        (esrgan/train_esrgan.py:203-204): loadable by a stock Adam over the same parameters."""
+        state, off = {}, 0
+        if self.step_count > 0:
+            for i, shp in enumerate(self.shapes):
+                n = math.prod(shp)
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[off:off + n].view(shp).clone(),
+                            "exp_avg_sq": self.v[off:off + n].view(shp).clone()}
+                off += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self.shapes)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Accepts a state_dict written by this class or by ``torch.optim.Adam`` over the same
+        parameters (one parameter group, as the reference uses)."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.shapes):
+            raise ValueError("optimizer state_dict does not match: expected one group of "
+                             f"{len(self.shapes)} parameters")
+        g = groups[0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.wd = g.get("weight_decay", 0.0)
+        self.m.zero_()
+        self.v.zero_()
+        steps, off = set(), 0
+        for i, shp in enumerate(self.shapes):
+            n = math.prod(shp)
+            st = sd["state"].get(i)
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != shp:
+                    raise ValueError(f"optimizer state for parameter {i} has shape "
+                                     f"{tuple(st['exp_avg'].shape)}, expected {shp}")
+                self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            off += n
+        if len(steps) > 1:
+            raise ValueError("parameters with different step counts cannot share one flat Adam state")
+        self.step_count = steps.pop() if steps else 0
 
     def step(self, flat_grad: torch.Tensor, grad_scale: float = 1.0):
         self.step_count += 1
@@ -75,7 +125,7 @@ class GeneratorWarmupTrainer:
                                                    accumulate_grads=(i > 0), **kw))
         self.plan = self.plans[0]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
-        self.opt = FlatAdam(self.flat, lr=lr)
+        self.opt = FlatAdam(self.flat, lr=lr, shapes=[p.shape for p in gen.parameters()])
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self.grad_sync = grad_sync
         self.steps = 0
@@ -173,8 +223,8 @@ class AdversarialTrainer:
         self.v_real = chain.VGGFeaturePlan(vparams, B, H, W, compute_dtype, need_input_grad=False)
         self.v_fake.run_packing()
         self.v_real.run_packing()                 # frozen weights: packed once
-        self.opt_g = FlatAdam(self.flat_g, lr=lr)
-        self.opt_d = FlatAdam(self.flat_d, lr=lr)
+        self.opt_g = FlatAdam(self.flat_g, lr=lr, shapes=[p.shape for p in gen.parameters()])
+        self.opt_d = FlatAdam(self.flat_d, lr=lr, shapes=[p.shape for p in disc.parameters()])
         self.acc = torch.zeros(4, dtype=torch.float32, device=dev)   # loss_disc, adv, l1, vgg
         self.grad_sync_g, self.grad_sync_d = grad_sync_g, grad_sync_d
         self.steps = 0

@@ -111,12 +111,44 @@ def test_native_trainer_bf16_runs_and_is_close_to_fp32():
         assert abs(res[torch.bfloat16][k] - v) / max(abs(v), 1e-6) < 5e-2, (k, res[torch.bfloat16][k], v)
 
 
-def test_cosine_lr_matches_torch_scheduler():
+def test_warmup_trainer_resumes_from_checkpoint(tmp_path):
+    """Generator + FlatAdam state through the reference's file layouts, then one more step:
+    the resumed trainer must continue exactly where the first one was."""
     T = pkg("train")
-    p = torch.nn.Parameter(torch.zeros(1))
-    opt = torch.optim.Adam([p], lr=2e-4)
-    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=1000, eta_min=1e-7)
-    for epoch in range(1, 6):
-        opt.step()
-        sch.step()
-        assert abs(T.cosine_lr(2e-4, epoch) - opt.param_groups[0]["lr"]) < 1e-12
+    CK = pkg("utils.checkpointing")
+    G = pkg("esrgan.generator")
+    g1 = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=5).cuda()
+    t1 = T.GeneratorWarmupTrainer(g1, (2, 3, 16, 16), torch.float32, lr=2e-4)
+    batches = [(O.hash_input(f"rs.lr{s}", (2, 3, 16, 16)).cuda(), O.hash_input(f"rs.hr{s}", (2, 3, 64, 64)).cuda())
+               for s in range(3)]
+    for lr, hr in batches[:2]:
+        t1.step(lr, hr)
+    CK.save_checkpoints(g1, t1.opt, 0, best_psnr=0.0, psnr=1.0, checkpoint_dir=tmp_path)
+    g2 = G.GeneratorESRGAN(num_blocks=1).cuda()
+    t2 = T.GeneratorWarmupTrainer(g2, (2, 3, 16, 16), torch.float32, lr=1.0)
+    assert CK.load_latest_checkpoint(g2, t2.opt, tmp_path) == 1
+    assert t2.opt.step_count == 2 and t2.opt.lr == 2e-4
+    t1.mean_loss()
+    t1.step(*batches[2])
+    t2.step(*batches[2])
+    assert abs(t1.mean_loss() - t2.mean_loss()) < 1e-6
+    for (n, a), (_, b) in zip(g1.named_parameters(), g2.named_parameters()):
+        assert float((a - b).abs().max()) < 2e-5, n          # one Adam step moves a weight by ~lr
+
+
+def test_validator_psnr_matches_oracle():
+    V = pkg("validate")
+    G = pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=9).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+    loader = [(O.hash_input(f"val.lr{i}", (4, 3, 12, 12)), O.hash_input(f"val.hr{i}", (4, 3, 48, 48)))
+              for i in range(2)]
+    g.train()
+    res = V.Validator(g, torch.float32).validate_one_epoch(loader)
+    assert g.training                                           # mode restored (train_esrgan.py:70)
+    sr = [float(O.psnr_unit_peak(O.generator_forward(lr, sd), hr)) for lr, hr in loader]
+    bi = [float(O.psnr_unit_peak(torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic",
+                                                                 align_corners=False), hr)) for lr, hr in loader]
+    assert abs(res["val_sr_psnr"] - sum(sr) / 2) < 1e-3
+    assert abs(res["val_bicubic_psnr"] - sum(bi) / 2) < 1e-3
+    assert abs(res["improvement"] - 100 * (1 - (sum(sr) / 2) / (sum(bi) / 2))) < 1e-2
