@@ -131,7 +131,7 @@ def main():
     gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
     adv = args.workload == "c3"
     B, h = args.batch, args.patch or (32 if adv else 64)
-    sync = D.FlatGradAllReduce(world) if world > 1 else None
+    sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0) if world > 1 else None
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
     if args.wgrad_rdbs is not None:
         E.GeneratorPlan.trunk_wgrad_rdbs = args.wgrad_rdbs

@@ -346,9 +346,11 @@ class Plan:
             arr = (L.UnpackItem * len(self.unpack_items))(*self.unpack_items)
             self._unpack_dev = self.upload(arr)
 
-    def run_unpack(self):
+    def run_unpack(self, first: int = 0, count: Optional[int] = None):
+        """Unpack table entries [first, first+count) (default: all) on the current stream."""
         if self._unpack_dev is not None:
-            L.check(self.lib.srx_unpack_wgrad(self._unpack_dev.data_ptr(), len(self.unpack_items),
+            count = len(self.unpack_items) - first if count is None else count
+            L.check(self.lib.srx_unpack_wgrad(self._unpack_dev.data_ptr() + first * C.sizeof(L.UnpackItem), count,
                                               self.unpack_max, stream_ptr(self.device)), "srx_unpack_wgrad")
 
     # --------------------------------------------------------------- run
@@ -369,31 +371,36 @@ class Plan:
     # its workgroups share the CUs with the chain's (one wave per SIMD each) and fill the MFMA
     # issue slots the chain's short launches leave idle.
     @staticmethod
-    def split_ops(main: "OpList", side_marks: List[Tuple[int, "OpList"]]):
-        """main: ops of the chain; side_marks: (number of chain ops that must precede, ops).
-        Returns (segments, serial ops, serial meta): segments = [(chain ops, side ops|None)],
-        the serial list interleaves both in dependency order for one-stream profiling."""
+    def split_ops(main: "OpList", side_marks: List[Tuple[int, "OpList", List[str]]]):
+        """main: ops of the chain; side_marks: (number of chain ops that must precede, ops,
+        names of the parameters whose gradients those ops complete).
+        Returns (segments, serial ops, serial meta, names per segment): segments =
+        [(chain ops, side ops|None)]; the serial list interleaves both in dependency order
+        for one-stream profiling."""
         segs, serial, meta = [], [], []
         pos = 0
-        for after, ops in side_marks:
+        for after, ops, names in side_marks:
             if after > pos or not segs:
                 chunk = main[pos:after]
-                segs.append([list(chunk), list(ops)])
+                segs.append([list(chunk), list(ops), list(names)])
                 serial += chunk
                 meta += main.meta[pos:after]
                 pos = after
             else:
                 segs[-1][1] += list(ops)
+                segs[-1][2] += list(names)
             serial += ops
             meta += ops.meta
         if pos < len(main) or not segs:
-            segs.append([list(main[pos:]), []])
+            segs.append([list(main[pos:]), [], []])
             serial += main[pos:]
             meta += main.meta[pos:]
-        frozen = [(Plan.freeze(a), Plan.freeze(b)) for a, b in segs]
-        return frozen, Plan.freeze(serial), meta
+        frozen = [(Plan.freeze(a), Plan.freeze(b)) for a, b, _ in segs]
+        return frozen, Plan.freeze(serial), meta, [n for _, _, n in segs]
 
-    def run_split(self, segments) -> None:
+    def run_split(self, segments, side_hook=None) -> None:
+        """side_hook(i), if given, is called with the side stream current right after segment
+        i's side ops were enqueued (gradient exchange of what they completed)."""
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
@@ -410,6 +417,9 @@ class Plan:
                 ev.record(main)
                 side.wait_event(ev)
                 self.run(aside, stream=side)
+                if side_hook is not None:
+                    with torch.cuda.stream(side):
+                        side_hook(i)
                 used = True
         if used:
             self._side_done.record(side)
@@ -558,11 +568,47 @@ class _GenBase(Plan):
     # ---- shared run API ---------------------------------------------------
     bwd_segments = None     # two-stream form of bwd_ops (Plan.split_ops), when the plan built one
 
-    def run_backward_ops(self) -> None:
-        if self.bwd_segments is not None:
-            self.run_split(self.bwd_segments)
-        else:
+    bwd_seg_ranges = None   # per segment: [(first item, item count, flat offset, flat end)] completed by it
+
+    def run_backward_ops(self, on_grads_ready=None) -> bool:
+        """Run the backward op lists.  on_grads_ready(lo, hi), if given and the plan has the
+        two-stream form, is called (side stream current) as soon as flat_grad[lo:hi] is final
+        and unpacked — the hook a data-parallel exchange overlaps with the rest of backward.
+        Returns True if the gradients were delivered that way (run_unpack is then not needed)."""
+        if self.bwd_segments is None:
             self.run(self.bwd_ops)
+            return False
+        if on_grads_ready is None or self.bwd_seg_ranges is None:
+            self.run_split(self.bwd_segments)
+            return False
+
+        def hook(i):
+            for first, count, lo, hi in self.bwd_seg_ranges[i]:
+                self.run_unpack(first, count)
+                on_grads_ready(lo, hi)
+        self.run_split(self.bwd_segments, hook)
+        return True
+
+    def _ranges_for(self, seg_names: List[List[str]]):
+        """Contiguous runs of unpack items / flat-gradient offsets for each segment's names."""
+        index = {n: i for i, n in enumerate(self.param_names)}
+        sizes = [self.grads[n].numel() for n in self.param_names]
+        out, seen = [], set()
+        for names in seg_names:
+            idx = sorted(index[n] for n in names)
+            seen.update(idx)
+            runs, k = [], 0
+            while k < len(idx):
+                j = k
+                while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+                    j += 1
+                lo = self._soff[self.param_names[idx[k]]]
+                hi = self._soff[self.param_names[idx[j]]] + sizes[idx[j]]
+                runs.append((idx[k], idx[j] - idx[k] + 1, lo, hi))
+                k = j + 1
+            out.append(runs)
+        assert seen == set(range(len(self.param_names))), "a parameter's gradient is completed by no segment"
+        return out
 
     def backward_c8(self) -> None:
         self.run_backward_ops()
@@ -657,38 +703,40 @@ class GeneratorPlan(_GenBase):
         self.gfeat = self.buf(B, nf, h, w)
         self.gX0 = self.buf(B, in_ch, h, w) if self.need_input_grad else None
 
-        side_marks: List[Tuple[int, OpList]] = []
+        side_marks: List[Tuple[int, OpList, List[str]]] = []
 
-        def aside(emit):
+        def aside(emit, names):
             """Record a weight-gradient launch that may start once every chain op recorded so
-            far has run."""
+            far has run; names: the parameters whose gradients it completes."""
             if self.overlap_wgrad:
                 ops = OpList()
                 emit(ops)
-                side_marks.append((len(bwd), ops))
+                side_marks.append((len(bwd), ops, names))
             else:
                 emit(bwd)
 
+        wb = lambda layer: [layer + ".weight", layer + ".bias"]
+
         # conv_last: GY -> gV, masked by LeakyReLU'(V)               (esrgan/generator.py:71)
-        aside(lambda o: self.layer_wgrad(o, P, "conv_last", (self.V, 0), (self.GY, 0), B, H4, W4))
+        aside(lambda o: self.layer_wgrad(o, P, "conv_last", (self.V, 0), (self.GY, 0), B, H4, W4), wb("conv_last"))
         self.conv(bwd, (self.GY, 0), (self.gV, 0), self.dgrad_layer(P, "conv_last", nf), 0, B, H4, W4,
                   out_ch, nf, mask=(self.V, 0), mask_slope=LRELU)
         # conv_hr: gV -> gU1, masked by LeakyReLU'(U1) (activation of upsample.1, :48)
-        aside(lambda o: self.layer_wgrad(o, P, "conv_hr", (self.U1, 0), (self.gV, 0), B, H4, W4))
+        aside(lambda o: self.layer_wgrad(o, P, "conv_hr", (self.U1, 0), (self.gV, 0), B, H4, W4), wb("conv_hr"))
         self.conv(bwd, (self.gV, 0), (self.gU1, 0), self.dgrad_layer(P, "conv_hr", nf), 0, B, H4, W4,
                   nf, nf, mask=(self.U1, 0), mask_slope=LRELU)
         # upsample.1: inverse shuffle, then conv backward, masked by LeakyReLU'(U0)
         self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU1, 0), c=(self.gyu1, 0), B=B, C_=nf, H=2 * h, W=2 * w)
-        aside(lambda o: self.layer_wgrad(o, P, "upsample.1.conv", (self.U0, 0), (self.gyu1, 0), B, 2 * h, 2 * w))
+        aside(lambda o: self.layer_wgrad(o, P, "upsample.1.conv", (self.U0, 0), (self.gyu1, 0), B, 2 * h, 2 * w), wb("upsample.1.conv"))
         self.conv(bwd, (self.gyu1, 0), (self.gU0, 0), self.dgrad_layer(P, "upsample.1.conv", nf), 0, B,
                   2 * h, 2 * w, 4 * nf, nf, mask=(self.U0, 0), mask_slope=LRELU)
         # upsample.0 (its input T1 = feat + trunk has no activation)
         self.generic(bwd, L.OP_PIXEL_UNSHUFFLE, a=(self.gU0, 0), c=(self.gyu0, 0), B=B, C_=nf, H=h, W=w)
-        aside(lambda o: self.layer_wgrad(o, P, "upsample.0.conv", (self.T1, 0), (self.gyu0, 0), B, h, w))
+        aside(lambda o: self.layer_wgrad(o, P, "upsample.0.conv", (self.T1, 0), (self.gyu0, 0), B, h, w), wb("upsample.0.conv"))
         self.conv(bwd, (self.gyu0, 0), (self.gT1, 0), self.dgrad_layer(P, "upsample.0.conv", nf), 0, B, h, w,
                   4 * nf, nf)
         # conv_body: gT1 -> gradient of the last RRDB's output
-        aside(lambda o: self.layer_wgrad(o, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w))
+        aside(lambda o: self.layer_wgrad(o, P, "conv_body", (Rb(nR), 0), (self.gT1, 0), B, h, w), wb("conv_body"))
         last_dst = (self.G[nR - 1], g8) if nR else (self.gfeat, 0)
         self.conv(bwd, (self.gT1, 0), last_dst, self.dgrad_layer(P, "conv_body", nf), 0, B, h, w, nf, nf)
 
@@ -697,24 +745,26 @@ class GeneratorPlan(_GenBase):
         # order keeps one block's buffers hot in L2.
         per_launch = self.trunk_wgrad_rdbs if (self.overlap_wgrad and self.trunk_wgrad_rdbs > 0) else nR
         pending: list = []
+        pending_names: List[str] = []
         n_pending = 0
 
         def flush():
-            nonlocal pending, n_pending
+            nonlocal pending, pending_names, n_pending
             if not pending:
                 return
-            tasks, nblocks = pending, n_pending
-            pending, n_pending = [], 0
+            tasks, nblocks, names = pending, n_pending, pending_names
+            pending, pending_names, n_pending = [], [], 0
             per_block = len(tasks) // nblocks
             aside(lambda o: self.wgrad(o, None, None, tasks, B, h, w, nslices=self.trunk_wgrad_slices,
                                        x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
-                                       group=per_block if per_block * nblocks == len(tasks) else 0))
+                                       group=per_block if per_block * nblocks == len(tasks) else 0), names)
 
         for r in range(nR - 1, -1, -1):
             blk, q = divmod(r, 3)
             dst = (self.G[r - 1], g8) if r > 0 else (self.gfeat, 0)
             self.emit_rdb_bwd(bwd, P, f"body.{blk}.rdb{q + 1}.", Rb(r), self.G[r], dst, B, h, w, nf, gc, q,
                               (self.G[r + 2], g8) if q == 0 else None, defer_wgrad=pending)
+            pending_names += [f"body.{blk}.rdb{q + 1}.conv{k}.{t}" for k in range(1, 6) for t in ("weight", "bias")]
             n_pending += 1
             if n_pending == per_launch:
                 flush()
@@ -722,12 +772,13 @@ class GeneratorPlan(_GenBase):
         # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
         self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
                      n=self.gfeat.t.numel())
-        aside(lambda o: self.layer_wgrad(o, P, "conv_first", (self.X0, 0), (self.gfeat, 0), B, h, w))
+        aside(lambda o: self.layer_wgrad(o, P, "conv_first", (self.X0, 0), (self.gfeat, 0), B, h, w), wb("conv_first"))
         if self.need_input_grad:
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
         if self.overlap_wgrad:
-            self.bwd_segments, self.bwd_ops, self.bwd_meta = self.split_ops(bwd, side_marks)
+            self.bwd_segments, self.bwd_ops, self.bwd_meta, seg_names = self.split_ops(bwd, side_marks)
+            self.bwd_seg_ranges = self._ranges_for(seg_names)
         else:
             self.bwd_ops = self.freeze(bwd)
             self.bwd_meta = bwd.meta

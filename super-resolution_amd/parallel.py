@@ -15,6 +15,15 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged_sum(t: torch.Tensor, group) -> None:
+    """Sum a device tensor over a gloo group through a host copy.  Only rehearsals of the
+    multi-rank path on a single GPU come here (RCCL needs one GPU per rank); gloo's own
+    device-tensor collectives stall intermittently when two ranks share one GPU."""
+    h = t.detach().cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+
+
 class FlatGradAllReduce:
     """Average a flat gradient buffer over the ranks in buckets.
 
@@ -34,13 +43,68 @@ class FlatGradAllReduce:
     def __call__(self, flat_grad: torch.Tensor) -> None:
         if self.world == 1:
             return
-        avg = dist.ReduceOp.AVG if flat_grad.is_cuda else dist.ReduceOp.SUM
-        works = [dist.all_reduce(flat_grad[s], op=avg, group=self.group, async_op=True)
-                 for s in self.buckets(flat_grad.numel())]
+        use_avg = dist.get_backend(self.group) == "nccl"        # gloo has no AVG
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        works = []
+        for s in self.buckets(flat_grad.numel()):
+            if flat_grad.is_cuda and not use_avg:
+                _host_staged_sum(flat_grad[s], self.group)
+            else:
+                works.append(dist.all_reduce(flat_grad[s], op=op, group=self.group, async_op=True))
         for w in works:
             w.wait()
-        if not flat_grad.is_cuda:
+        if not use_avg:
             flat_grad.div_(self.world)
+
+
+class OverlappedGradAllReduce(FlatGradAllReduce):
+    """The same average, issued piecewise while backward is still running.
+
+    ``begin(flat)`` once per step; ``ready(lo, hi)`` whenever ``flat[lo:hi]`` is final — called
+    with the stream that produced it current, so the collective (which runs on the process
+    group's stream behind an event on the current stream) starts as soon as that range is
+    written and overlaps everything backward still has to do; ``finish()`` before the
+    optimizer step.  Adjacent ranges are merged until a bucket is full: backward completes the
+    generator's gradients from the last layer to the first, so buckets fill in reverse
+    parameter order."""
+
+    def begin(self, flat_grad: torch.Tensor) -> None:
+        self._flat = flat_grad
+        self._works = []
+        self._pending: Optional[List[int]] = None
+        backend = dist.get_backend(self.group) if self.world > 1 else ""
+        self._avg = backend == "nccl"
+
+    def _flush(self) -> None:
+        if self._pending is None:
+            return
+        lo, hi = self._pending
+        self._pending = None
+        if self.world > 1:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            if self._flat.is_cuda and not self._avg:
+                _host_staged_sum(self._flat[lo:hi], self.group)
+            else:
+                self._works.append(dist.all_reduce(self._flat[lo:hi], op=op, group=self.group, async_op=True))
+
+    def ready(self, lo: int, hi: int) -> None:
+        if self._pending is not None and hi == self._pending[0]:
+            self._pending[0] = lo
+        elif self._pending is not None and lo == self._pending[1]:
+            self._pending[1] = hi
+        else:
+            self._flush()
+            self._pending = [lo, hi]
+        if self._pending[1] - self._pending[0] >= self.bucket_elems:
+            self._flush()
+
+    def finish(self) -> None:
+        self._flush()
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.world > 1 and not self._avg:
+            self._flat.div_(self.world)
 
 
 def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:

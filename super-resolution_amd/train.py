@@ -93,6 +93,22 @@ class FlatAdam:
                                  self.step_count, grad_scale, engine.stream_ptr(self.p.device)), "srx_adam")
 
 
+def _backward_with_exchange(plan, grad_sync) -> bool:
+    """Backward + unpack of a generator plan.  With an exchange object that has the
+    begin/ready/finish protocol (parallel.OverlappedGradAllReduce) and a two-stream plan, each
+    gradient range is unpacked and handed to the exchange as soon as its weight-gradient
+    launches are enqueued; returns True when the exchange has been done that way."""
+    if grad_sync is not None and hasattr(grad_sync, "ready") and plan.bwd_seg_ranges is not None:
+        grad_sync.begin(plan.flat_grad)
+        if plan.run_backward_ops(grad_sync.ready):
+            grad_sync.finish()
+            return True
+    else:
+        plan.run_backward_ops()
+    plan.run_unpack()
+    return False
+
+
 class GeneratorWarmupTrainer:
     """Generator warm-up: L1 pixel loss, fwd + bwd + Adam (BASELINE config 2).
 
@@ -135,14 +151,17 @@ class GeneratorWarmupTrainer:
         L.check(p.lib.srx_l1_c8_nchw(p.dt, Y.ptr(), Y.img_stride, hr_img.data_ptr(), self.loss_acc.data_ptr(),
                                      p.GY.ptr(), p.GY.img_stride, 1.0 / self.n_streams, Y.B, p.out_ch, Y.H, Y.W,
                                      engine.stream_ptr(p.device)), "srx_l1_c8_nchw")
+        if self.n_streams == 1:
+            return _backward_with_exchange(p, self.grad_sync)
         p.run_backward_ops()
+        return False
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
         hr_img = hr_img.contiguous()
         lr_img = lr_img.contiguous()
+        exchanged = False
         if self.n_streams == 1:
-            self._sub_step(self.plan, lr_img, hr_img)
-            self.plan.run_unpack()
+            exchanged = self._sub_step(self.plan, lr_img, hr_img)
         else:
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
@@ -161,7 +180,7 @@ class GeneratorWarmupTrainer:
             for p in self.plans:          # plan 0 writes, the others accumulate
                 p.run_unpack()
         g = self.plan.flat_grad
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and not exchanged:
             self.grad_sync(g)
         self.opt.step(g)
         self.steps += 1
@@ -283,10 +302,9 @@ class AdversarialTrainer:
         n = gp.GY.t.numel()
         for src in (dg.gA[0], vf.gA[0]):           # dL/dfake = sum of the three branches
             L.check(lib.srx_axpby(gp.dt, src.ptr(), gp.GY.ptr(), 1.0, 1.0, n, sp), "srx_axpby")
-        gp.run_backward_ops()
-        gp.run_unpack()
+        exchanged = _backward_with_exchange(gp, self.grad_sync_g)
         gg = gp.flat_grad
-        if self.grad_sync_g is not None:
+        if self.grad_sync_g is not None and not exchanged:
             self.grad_sync_g(gg)
         self.opt_g.step(gg)
         self.steps += 1
