@@ -37,7 +37,7 @@ int srx_version(void);
 const char* srx_last_error(void);
 /* sizeof() of the ABI structs, for binding self-checks: 0 srx_conv_desc, 1 srx_wgrad_task,
  * 2 srx_wgrad_desc, 3 srx_pack_seg, 4 srx_pack_layer, 5 srx_unpack_item, 6 srx_sn_layer,
- * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile; -1 for an unknown id. */
+ * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop; -1 for an unknown id. */
 int srx_sizeof(int which);
 
 /* ------------------------------------------------------------------ layout */
@@ -280,6 +280,21 @@ int srx_tile_gather(int dtype, const float* img, int C, int h, int w, const srx_
 int srx_tile_blend(int dtype, const void* store, const srx_tile* tiles /*DEVICE*/, int ny, int nx,
                    int stride, int tile, int scale, const float* window, float* out, uint8_t* out_u8,
                    int C, int OH, int OW, int clamp01, void* stream);
+
+/* ------------------------------------------------------------ batch former */
+/* One sample of the training loader, reference utils/datasets.py:77-114 (TrainDataset.
+ * __getitem__): crop [y0,y0+size) x [x0,x0+size) of a decoded uint8 RGB image (HWC, device
+ * memory), then hflip (flags bit 0), vflip (bit 1), then (flags>>2)&3 counter-clockwise
+ * quarter turns (PIL's rotate by 90/180/270 on a square patch), then ToTensor (/255) and
+ * Normalize(mean 0.5, std 0.5).  The host draws the random decisions; the LR and HR sample
+ * of a pair use the same flags and y0, x0 scaled by 4 (:92-96).  The crop must lie inside
+ * the image (checked by the caller: the table is in device memory). */
+typedef struct srx_crop {
+  const uint8_t* img;
+  int32_t H, W, y0, x0, flags, pad_;
+} srx_crop;
+/* out: fp32 [B][3][size][size]; crops: DEVICE array of B entries. */
+int srx_crop_augment(const srx_crop* crops /*DEVICE*/, int B, int size, float* out, void* stream);
 
 /* ------------------------------------------------------------ batched ops */
 #define SRX_OP_CONV 1

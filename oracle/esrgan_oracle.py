@@ -386,3 +386,20 @@ def infer_tiled(lr: Tensor, model_fn, tile: int, overlap: int, scale: int = 4,
         wsum[:, :, ys:ys + sh, xs:xs + sw] += win[:, :, :sh, :sw]
     out = sr / (wsum + 1e-8)
     return out[:, :, :h * scale, :w * scale]
+
+
+# ---------------------------------------------------------------------------
+# Training-pair augmentation (reference utils/datasets.py:77-114, after decoding)
+# ---------------------------------------------------------------------------
+def crop_augment(img_u8: np.ndarray, y0: int, x0: int, size: int, hflip: bool, vflip: bool,
+                 quarter_turns: int) -> Tensor:
+    """TF.crop -> TF.hflip -> TF.vflip -> TF.rotate(90*k, counter-clockwise, square patch) ->
+    ToTensor -> Normalize(0.5, 0.5) on a uint8 [H,W,3] array; returns fp32 [3,size,size]."""
+    p = img_u8[y0:y0 + size, x0:x0 + size]
+    if hflip:
+        p = p[:, ::-1]
+    if vflip:
+        p = p[::-1]
+    p = np.rot90(p, quarter_turns, axes=(0, 1))
+    t = torch.from_numpy(np.ascontiguousarray(p)).permute(2, 0, 1).to(torch.float32).div(255)
+    return t.sub(0.5).div(0.5)

@@ -86,6 +86,10 @@ class Tile(C.Structure):
     _fields_ = [("y0", i32), ("x0", i32), ("th", i32), ("tw", i32), ("offset", i64)]
 
 
+class Crop(C.Structure):
+    _fields_ = [("img", vp), ("H", i32), ("W", i32), ("y0", i32), ("x0", i32), ("flags", i32), ("pad_", i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs)]
 
@@ -126,6 +130,7 @@ _SIGS = {
     "srx_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
     "srx_run_ops": (C.c_int, [vp, C.c_int, vp]),
     "srx_tile_gather": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
+    "srx_crop_augment": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "srx_tile_blend": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                  C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }
@@ -149,7 +154,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         structs = (ConvDesc, WgradTask, WgradDesc, PackSeg, PackLayer, UnpackItem, SnLayer,
-                   SnBwdLayer, GenericArgs, Op, Tile)
+                   SnBwdLayer, GenericArgs, Op, Tile, Crop)
         for i, st in enumerate(structs):
             if l.srx_sizeof(i) != C.sizeof(st):
                 raise RuntimeError(f"libsrx ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in "

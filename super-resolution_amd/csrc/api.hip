@@ -33,6 +33,7 @@ int srx_sizeof(int which) {
     case 8: return (int)sizeof(srx_generic_args);
     case 9: return (int)sizeof(srx_op);
     case 10: return (int)sizeof(srx_tile);
+    case 11: return (int)sizeof(srx_crop);
     default: return -1;
   }
 }

@@ -109,3 +109,42 @@ extern "C" int srx_tile_blend(int dtype, const void* store, const srx_tile* tile
     SRX_CHECK_ARG(false, "srx_tile_blend: bad dtype %d", dtype);
   return srx_check_launch("tile_blend");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Training-batch former (reference utils/datasets.py:77-114): synchronized crop of a decoded
+// uint8 HWC image, hflip, vflip, quarter-turn rotation, ToTensor (/255) and Normalize
+// ((x-0.5)/0.5), written as one fp32 NCHW batch entry.  One thread per output pixel walks the
+// augmentation chain backwards to its source pixel.
+namespace {
+
+__global__ void crop_augment_kernel(const srx_crop* __restrict__ crops, int S, float* __restrict__ out) {
+  const srx_crop c = crops[blockIdx.y];
+  const int n = S * S;
+  float* o = out + (long)blockIdx.y * 3 * n;
+  const int turns = (c.flags >> 2) & 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int y = i / S, x = i % S;
+    for (int t = 0; t < turns; ++t) {      // undo one counter-clockwise quarter turn
+      const int ny = x, nx = S - 1 - y;
+      y = ny; x = nx;
+    }
+    if (c.flags & 2) y = S - 1 - y;        // vflip
+    if (c.flags & 1) x = S - 1 - x;        // hflip
+    const uint8_t* px = c.img + ((long)(c.y0 + y) * c.W + (c.x0 + x)) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float v = __fdiv_rn((float)px[ch], 255.0f);
+      o[(long)ch * n + i] = __fdiv_rn(v - 0.5f, 0.5f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int srx_crop_augment(const srx_crop* crops, int B, int size, float* out, void* stream) {
+  SRX_CHECK_ARG(crops && out && B > 0 && size > 0, "srx_crop_augment: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for((long)size * size, 256), B);
+  hipLaunchKernelGGL(crop_augment_kernel, grid, dim3(TPB), 0, s, crops, size, out);
+  return srx_check_launch("crop_augment");
+}
