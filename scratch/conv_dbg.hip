@@ -8,8 +8,8 @@
 // every LDS fragment read is one 16-byte slot per lane.
 //
 // One workgroup = 4 waves = (4*RW) groups of 32 output pixels x (32*NB) couts.
-// K loop over 16-channel chunks through a 3-stage LDS ring filled by LDS-DMA
-// (buffer_load ... lds): chunk c+2 streams in while chunk c is multiplied; one
+// K loop over 16-channel chunks through a 2- or 3-stage LDS ring filled by LDS-DMA
+// (buffer_load ... lds): later chunks stream in while chunk c is multiplied; one
 // counted s_waitcnt vmcnt + one raw s_barrier per chunk.
 //
 // Epilogue (bias, derivative mask, LeakyReLU/ReLU, residual scaling, optional
@@ -17,6 +17,12 @@
 // the 32 rows of a block so each lane's registers 0..7 / 8..15 are two whole
 // output octets, stored with 16-byte writes and no cross-lane traffic.
 #include "srx_common.h"
+
+__device__ unsigned long long g_stamps[1024 * 8];
+extern "C" int srx_dbg_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 8);
+}
+#define STAMP(k) do { if (threadIdx.x == 0) g_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 namespace {
 
@@ -66,7 +72,16 @@ __device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, _
 }
 
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+struct RingDepth {
+  // fp32 tiles are twice as large; the two-block and four-row-group tiles stay at two stages so
+  // that two workgroups (or one plus a weight-gradient workgroup) still fit a CU's 160 KB
+  static constexpr int value = (sizeof(T) == 2 && NB == 1 && RW <= 2) ? 3 : 2;
+};
+
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_kernel(const ConvParams p) {
+  // (bf16: at most 256 registers, so a convolution workgroup and a weight-gradient workgroup
+  //  of the other stream fit one SIMD's register file together)
   typedef typename Frag<T>::type frag_t;
   constexpr int TW = 1 << LTW;
   constexpr int RPG = 32 >> LTW;            // rows per 32-pixel group
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   constexpr int NWS = (WP + 255) / 256;
   constexpr int XPP = NXS * 256, WPP = NWS * 256;   // stage regions padded to whole wave instructions
   constexpr int STAGE = XPP + WPP;          // 16-byte slots per ring stage
-  constexpr int NSTG = sizeof(T) == 2 ? 3 : 2;   // ring depth (fp32 tiles are twice as large)
+  constexpr int NSTG = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value;   // ring depth
   constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
   constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
   static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
@@ -92,27 +107,42 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
   extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];   // NSTG ring stages
 
-#ifdef DBG_EMPTY
-  if (p.H > 0) return;
-#endif
+  // Convolutions sit on the critical path of a layer chain; weight-gradient workgroups that
+  // share the CU (other stream) only fill the issue slots these waves leave idle.
+  __builtin_amdgcn_s_setprio(3);
+  STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int pl = lane & 31;                 // pixel / row index inside the MFMA tile
   const int hh = lane >> 5;                 // k half
 
-  int bid = blockIdx.x;
-  const int grp = bid % p.ngroups; bid /= p.ngroups;
-  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
-  const int ty = bid % p.tiles_y;
-  const int b = bid / p.tiles_y;
+  // grid = (tiles_x * ngroups, tiles_y, B): no run-time divisions on the way to the first load
+  // in the common single-group case
+  int tx = blockIdx.x, grp = 0;
+  if (p.ngroups > 1) { grp = tx % p.ngroups; tx /= p.ngroups; }
+  const int ty = blockIdx.y;
+  const int b = blockIdx.z;
   const int nb0 = grp * NB;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
   const long plane_in = (long)p.H * p.W * 8;
 
+  STAMP(1);
   const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
   const T* wb = reinterpret_cast<const T*>(p.w);
+
+  // The bias is the accumulators' initial value: a lane's 16 accumulator registers of block n
+  // are the packed-bias floats [(n*2+hh)*16, +16) (the packer's row order).  Loaded first, so
+  // these are the wave's oldest memory operations and have long landed when the loop starts.
+  f32x4 bias_v[NB][4];
+  if (p.bias) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        bias_v[n][k] = *reinterpret_cast<const f32x4*>(p.bias + ((nb0 + n) * 2 + hh) * 16 + k * 4);
+  }
 
   // ---- staging plan: LDS-DMA ring ----
   // Every chunk (16 input channels: the halo tile of two octet planes + the 9-tap weight block)
@@ -159,13 +189,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
                                        reinterpret_cast<char*>(smem + stage * STAGE), wave_u);
   };
 
-  f32x16 acc[RW][NB];
+  STAMP(2);
 #pragma unroll
-  for (int r = 0; r < RW; ++r)
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[r][n][i] = 0.f;
+  for (int j = 0; j < DIST; ++j)
+    if (j < p.nchunk) issue(j, j);
 
   // LDS slot (in octets) of this lane's pixel for row group rg at tap (0,0)
   int xslot[RW];
@@ -176,13 +203,48 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
   }
 
-#ifdef DBG_NOLOOP
-  if (p.H < 0) {
-#endif
+  // ---- epilogue addressing and operand prefetch state ----
+  // A convolution either masks its output by an activation derivative (data gradients inside
+  // a chain) or adds residuals (block outputs), in practice never both: each of the two
+  // common forms prefetches all its epilogue operands in one burst while the last chunk is
+  // being multiplied; the combination takes the plain path after the loop.
+  const long plane_out = (long)p.OH * p.OW * 8;
+  const bool all_octs = (nb0 + NB) * 4 <= p.cout8;
+  const bool fast_mask = all_octs && p.mask && !p.res1 && !p.res2 && !p.ps;
+  const bool fast_res = all_octs && !p.mask && p.res1 && !p.ps;
+  typedef typename Oct<T>::vec oct_t;
+  long eoff[RW];                       // element offset of (octet plane 0, this lane's pixel); -1: outside
 #pragma unroll
-  for (int j = 0; j < DIST; ++j)
-    if (j < p.nchunk) issue(j, j);
+  for (int rg = 0; rg < RW; ++rg) {
+    const int g = wave * RW + rg;
+    const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
+    eoff[rg] = (oy < p.OH && ox < p.OW) ? ((long)oy * p.OW + ox) * 8 : -1;
+  }
+  oct_t pre_a[RW][NB][2];              // mask or res1; re-used for res2
+  auto prefetch = [&](const T* base_a) {
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oct = (nb0 + n) * 4 + 2 * j + hh;
+          if (eoff[rg] < 0 || oct >= p.cout8) continue;
+          const long off = (long)oct * plane_out + eoff[rg];
+          pre_a[rg][n][j] = *reinterpret_cast<const oct_t*>(base_a + off);
+        }
+  };
+
+  f32x16 acc[RW][NB];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][n][i] = p.bias ? bias_v[n][i >> 2][i & 3] : 0.f;
+
   int stage = 0;
+  STAMP(3);
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
     // this chunk's DMA has landed (the DIST-1 younger chunks may stay in flight) ...
     if (DIST > 1 && chunk + DIST - 1 < p.nchunk)
@@ -190,9 +252,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // ... in every wave; and every wave is done with the previous stage
-#ifndef DBG_NODMA
+    if (chunk == 0) STAMP(4);
     if (chunk + DIST < p.nchunk) issue(chunk + DIST, stage == 0 ? NSTG - 1 : stage - 1);
-#endif
+    if (chunk + 1 == p.nchunk && (fast_mask || fast_res))   // this chunk waited for vmcnt(0): nothing counts after it
+      prefetch(reinterpret_cast<const T*>(fast_mask ? p.mask : p.res1) + (long)b * (fast_mask ? p.m_is : p.r1_is));
     const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
     const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
     // Fragment reads run one tap ROW (KS taps) ahead of the MFMAs that consume them: with one
@@ -208,7 +271,6 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
       }
     };
-#ifndef DBG_NOMMA
     read_row(0, 0);
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
@@ -219,91 +281,142 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg)
 #pragma unroll
-          for (int n = 0; n < NB; ++n) {
-#ifdef DBG_NOLDSREAD
-            mma(wf[0][0][0], xf[0][0][0], acc[rg][n]);
-#else
-            mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
-#endif
-          }
+          for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     stage = stage == NSTG - 1 ? 0 : stage + 1;
   }
 
-  // ---- epilogue ----
-#ifdef DBG_NOEPI
-  if (acc[0][0][0] != 12345.678f) return;
-#endif
-#ifdef DBG_NOLOOP
+  STAMP(5);
+  // One wave per SIMD issues an instruction every few cycles, so this straight-line tail is
+  // priced by its instruction count: every run-time option is tested ONCE per wave (uniform
+  // branches around whole passes over the accumulators), never per stored octet.
+  const bool full = (nb0 + NB) * 4 <= p.cout8 || p.ps;        // every octet of these blocks exists
+  const bool fast = full && !(p.mask && !fast_mask) && !((p.res1 || p.res2) && !fast_res);
+  if (fast) {
+    if (fast_mask) {
+      const float ms = p.mask_slope;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[rg][n][i] = (float)pre_a[rg][n][i >> 3][i & 7] > 0.f ? acc[rg][n][i] : acc[rg][n][i] * ms;
+    }
+    if (p.act_slope != 1.f) {          // LeakyReLU / ReLU, slope in [0,1): max(v, slope*v)
+      const float as = p.act_slope;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[rg][n][i] = (as >= 0.f && as <= 1.f) ? fmaxf(acc[rg][n][i], acc[rg][n][i] * as)
+                                                     : (acc[rg][n][i] > 0.f ? acc[rg][n][i] : acc[rg][n][i] * as);
+    }
+    if (p.alpha != 1.f) {
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[rg][n] *= p.alpha;
+    }
+    if (fast_res) {
+      const float b1 = p.beta1;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rg][n][i] += b1 * (float)pre_a[rg][n][i >> 3][i & 7];
+      if (p.res2) {                    // second residual: one more burst into the same registers
+        prefetch(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is);
+        const float b2 = p.beta2;
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rg][n][i] += b2 * (float)pre_a[rg][n][i >> 3][i & 7];
+      }
+    }
+    STAMP(6);
+    T* yb = reinterpret_cast<T*>(p.y) + (long)b * p.y_is;
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg) {
+      if (eoff[rg] < 0) continue;
+      T* yrow;
+      long ostep;                      // element step between consecutive stored octets (j, then n)
+      if (p.ps) {                      // PixelShuffle(2): sub-pixel (hh, j) of output channel block nb
+        const int g = wave * RW + rg;
+        const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
+        yrow = yb + (long)nb0 * 4 * plane_out + ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox) * 8;
+        ostep = 8;
+      } else {
+        yrow = yb + (long)(nb0 * 4 + hh) * plane_out + eoff[rg];
+        ostep = 2 * plane_out;
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
+          store_oct(yrow + (p.ps ? (long)n * 4 * plane_out + j * ostep : (long)(n * 2 + j) * ostep), v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);
+    return;
   }
-#endif
-  const long plane_out = (long)p.OH * p.OW * 8;
+  // general form (ragged channel counts, mask together with residuals): per stored octet
 #pragma unroll
   for (int rg = 0; rg < RW; ++rg) {
-    const int g = wave * RW + rg;
-    const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
-    if (oy >= p.OH || ox >= p.OW) continue;
+    if (eoff[rg] < 0) continue;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const int nb = nb0 + n;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        const int oct = nb * 4 + 2 * j + hh;
+        if (oct >= p.cout8) continue;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
-        if (p.bias) {
-          const float* bp = p.bias + (nb * 2 + hh) * 16 + j * 8;
-          f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
-          f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        const long off = (long)oct * plane_out + eoff[rg];
+        if (p.mask) {
+          float m[8];
+          load_oct(reinterpret_cast<const T*>(p.mask) + (long)b * p.m_is + off, m);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
         }
-        if (p.ps) {
-          if (nb >= p.cout8) continue;
-          T* yp = reinterpret_cast<T*>(p.y) + (long)b * p.y_is + (long)nb * 4 * plane_out +
-                  ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox + j) * 8;
-          if (p.act_slope != 1.f) {
+        if (p.act_slope != 1.f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
-          }
-          store_oct(yp, v);
-        } else {
-          const int oct = nb * 4 + 2 * j + hh;
-          if (oct >= p.cout8) continue;
-          const long off = (long)oct * plane_out + ((long)oy * p.OW + ox) * 8;
-          if (p.mask) {
-            float m[8];
-            load_oct(reinterpret_cast<const T*>(p.mask) + (long)b * p.m_is + off, m);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
-          }
-          if (p.act_slope != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
-          }
-          if (p.alpha != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-          }
-          if (p.res1) {
-            float r[8];
-            load_oct(reinterpret_cast<const T*>(p.res1) + (long)b * p.r1_is + off, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.beta1 * r[e];
-          }
-          if (p.res2) {
-            float r[8];
-            load_oct(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is + off, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.beta2 * r[e];
-          }
-          store_oct(reinterpret_cast<T*>(p.y) + (long)b * p.y_is + off, v);
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
         }
+        if (p.alpha != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        }
+        if (p.res1) {
+          float r[8];
+          load_oct(reinterpret_cast<const T*>(p.res1) + (long)b * p.r1_is + off, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.beta1 * r[e];
+        }
+        if (p.res2) {
+          float r[8];
+          load_oct(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is + off, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.beta2 * r[e];
+        }
+        store_oct(reinterpret_cast<T*>(p.y) + (long)b * p.y_is + off, v);
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(7);
 }
 
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
@@ -313,7 +426,7 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
   constexpr int PPO = Oct<T>::PPO;
   constexpr int XPP = ((2 * IH * IW * PPO + 255) / 256) * 256, WPP = ((NB * KS * KS * 64 * PPO + 255) / 256) * 256;
-  constexpr int LDS = (sizeof(T) == 2 ? 3 : 2) * (XPP + WPP) * 16;
+  constexpr int LDS = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value * (XPP + WPP) * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvParams p = p0;
   p.tiles_x = (p.OW + TW - 1) / TW;
@@ -326,9 +439,10 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  long grid = (long)p.tiles_x * p.tiles_y * B * p.ngroups;
-  SRX_CHECK_ARG(grid > 0 && grid < (1L << 31), "conv grid out of range");
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+  const long gx = (long)p.tiles_x * p.ngroups;
+  SRX_CHECK_ARG(gx > 0 && gx < (1L << 31) && p.tiles_y > 0 && p.tiles_y <= 65535 && B <= 65535,
+                "conv grid out of range (%ld x %d x %d)", gx, p.tiles_y, B);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)p.tiles_y, (unsigned)B), dim3(256), LDS, stream, p);
   return srx_check_launch("conv_kernel");
 }
 

@@ -16,6 +16,7 @@
 // PixelShuffle(2) scatter) runs on the accumulators; the weight packer orders
 // the 32 rows of a block so each lane's registers 0..7 / 8..15 are two whole
 // output octets, stored with 16-byte writes and no cross-lane traffic.
+#include <stdlib.h>
 #include "srx_common.h"
 
 namespace {
@@ -47,7 +48,7 @@ __device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
 }
 
 // Issue one chunk's LDS-DMA: NXS activation + NWS weight instructions per wave, no branches.
-template <typename T, int NXS, int NWS, int XPP>
+template <typename T, int NXS, int NWS, int XPP, int THREADS>
 __device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc,
                                                  const unsigned (&xoff)[NXS], const unsigned (&woff)[NWS],
                                                  unsigned xcoff, unsigned wcoff, char* ls, int wave_u) {
@@ -56,28 +57,39 @@ __device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, _
 #pragma unroll
   for (int i = 0; i < NXS; ++i) {
     const unsigned vo = xoff[i] == OOB ? OOB : xoff[i] + xcoff;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(ls + (i * 256 + wave_u * 64) * 16), 16, vo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(ls + (i * THREADS + wave_u * 64) * 16), 16, vo, 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < NWS; ++i) {
     const unsigned vo = woff[i] == OOB ? OOB : woff[i] + wcoff;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(ls + (XPP + i * 256 + wave_u * 64) * 16), 16, vo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(ls + (XPP + i * THREADS + wave_u * 64) * 16), 16, vo, 0, 0, 0);
   }
 }
 
-template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
+// Workgroup shape.  WAVES waves = PW pixel groups of waves x CW output-block groups: a wave owns RW
+// groups of 32 pixels x NB blocks of 32 output channels; the workgroup stages NB*CW blocks of
+// weights.  Four waves put one wave on each SIMD; the eight-wave shapes put two there, so that one
+// wave's staging issue, fragment reads and barrier waits run under the other's MFMAs — what small
+// problems (one workgroup per CU) need, since nothing else shares the CU with them.
+template <typename T, int NB, int RW, int WAVES, int CW>
 struct RingDepth {
   // fp32 tiles are twice as large; the two-block and four-row-group tiles stay at two stages so
   // that two workgroups (or one plus a weight-gradient workgroup) still fit a CU's 160 KB
-  static constexpr int value = (sizeof(T) == 2 && NB == 1 && RW <= 2) ? 3 : 2;
+  static constexpr int value = (sizeof(T) == 2 && NB * CW == 1 && RW * (WAVES / CW) <= 8) ? 3 : 2;
 };
 
-template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS, int WAVES = 4, int CW = 1>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 4 : (sizeof(T) == 2 ? 2 : 1)))
+void conv_kernel(const ConvParams p) {
+  // (register caps: 4-wave bf16 shapes at most 256, 8-wave shapes at most 128 per lane, so a
+  //  convolution workgroup and a weight-gradient workgroup of the other stream fit one SIMD's
+  //  register file together)
   typedef typename Frag<T>::type frag_t;
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int PW = WAVES / CW;            // pixel groups of waves
   constexpr int TW = 1 << LTW;
   constexpr int RPG = 32 >> LTW;            // rows per 32-pixel group
-  constexpr int TH = 4 * RW * RPG;
+  constexpr int TH = PW * RW * RPG;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
   constexpr int IH = (TH - 1) * STRIDE + KS;
@@ -86,12 +98,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   constexpr int PPO = Oct<T>::PPO;
   constexpr int EPP = 16 / sizeof(T);       // elements per 16-byte piece
   constexpr int XP = 2 * NPIX * PPO;
-  constexpr int WP = NB * TAPS * 64 * PPO;
-  constexpr int NXS = (XP + 255) / 256;
-  constexpr int NWS = (WP + 255) / 256;
-  constexpr int XPP = NXS * 256, WPP = NWS * 256;   // stage regions padded to whole wave instructions
+  constexpr int WP = NB * CW * TAPS * 64 * PPO;
+  constexpr int NXS = (XP + THREADS - 1) / THREADS;
+  constexpr int NWS = (WP + THREADS - 1) / THREADS;
+  constexpr int XPP = NXS * THREADS, WPP = NWS * THREADS;   // stage regions padded to whole workgroup instructions
   constexpr int STAGE = XPP + WPP;          // 16-byte slots per ring stage
-  constexpr int NSTG = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value;   // ring depth
+  constexpr int NSTG = RingDepth<T, NB, RW, WAVES, CW>::value;   // ring depth
   constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
   constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
   static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
@@ -108,18 +120,34 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   const int pl = lane & 31;                 // pixel / row index inside the MFMA tile
   const int hh = lane >> 5;                 // k half
 
-  int bid = blockIdx.x;
-  const int grp = bid % p.ngroups; bid /= p.ngroups;
-  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
-  const int ty = bid % p.tiles_y;
-  const int b = bid / p.tiles_y;
-  const int nb0 = grp * NB;
+  // grid = (tiles_x * ngroups, tiles_y, B): no run-time divisions on the way to the first load
+  // in the common single-group case
+  int tx = blockIdx.x, grp = 0;
+  if (p.ngroups > 1) { grp = tx % p.ngroups; tx /= p.ngroups; }
+  const int ty = blockIdx.y;
+  const int b = blockIdx.z;
+  const int pg = wave % PW;                 // this wave's pixel group ...
+  const int bg = wave / PW;                 // ... and output-block group inside the workgroup
+  const int nb0 = grp * (NB * CW);          // first block staged by the workgroup
+  const int nbw0 = nb0 + bg * NB;           // first block of this wave
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
   const long plane_in = (long)p.H * p.W * 8;
 
   const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
   const T* wb = reinterpret_cast<const T*>(p.w);
+
+  // The bias is the accumulators' initial value: a lane's 16 accumulator registers of block n
+  // are the packed-bias floats [(n*2+hh)*16, +16) (the packer's row order).  Loaded first, so
+  // these are the wave's oldest memory operations and have long landed when the loop starts.
+  f32x4 bias_v[NB][4];
+  if (p.bias) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        bias_v[n][k] = *reinterpret_cast<const f32x4*>(p.bias + ((nbw0 + n) * 2 + hh) * 16 + k * 4);
+  }
 
   // ---- staging plan: LDS-DMA ring ----
   // Every chunk (16 input channels: the halo tile of two octet planes + the 9-tap weight block)
@@ -137,11 +165,11 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   const unsigned wchunk_bytes = TAPS * 512 * sizeof(T);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(wb + (long)nb0 * p.nchunk * (TAPS * 512)), 0,
-      (int)((unsigned)NB * p.nchunk * wchunk_bytes), 0x00020000);
+      (int)((unsigned)(NB * CW) * p.nchunk * wchunk_bytes), 0x00020000);
   unsigned xoff[NXS], woff[NWS];
 #pragma unroll
   for (int i = 0; i < NXS; ++i) {
-    int piece = tid + i * 256;
+    int piece = tid + i * THREADS;
     int q = piece % PPO;
     int pix = (piece / PPO) % NPIX;
     int h = piece / (PPO * NPIX);
@@ -154,16 +182,62 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   }
 #pragma unroll
   for (int i = 0; i < NWS; ++i) {
-    int piece = tid + i * 256;
+    int piece = tid + i * THREADS;
     int nb = piece / (TAPS * 64 * PPO);
     int rem = piece % (TAPS * 64 * PPO);
     woff[i] = piece < WP ? (unsigned)nb * p.nchunk * wchunk_bytes + (unsigned)rem * 16u : OOB;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int chunk, int stage) {
-    conv_issue_chunk<T, NXS, NWS, XPP>(xrsrc, wrsrc, xoff, woff, (unsigned)chunk * 2u * plane_bytes,
+    conv_issue_chunk<T, NXS, NWS, XPP, THREADS>(xrsrc, wrsrc, xoff, woff, (unsigned)chunk * 2u * plane_bytes,
                                        (unsigned)chunk * wchunk_bytes,
                                        reinterpret_cast<char*>(smem + stage * STAGE), wave_u);
+  };
+
+  // first chunks on their way before anything else is set up
+#pragma unroll
+  for (int j = 0; j < DIST; ++j)
+    if (j < p.nchunk) issue(j, j);
+
+  // LDS slot (in octets) of this lane's pixel for row group rg at tap (0,0)
+  int xslot[RW];
+#pragma unroll
+  for (int rg = 0; rg < RW; ++rg) {
+    int g = pg * RW + rg;
+    int py = g * RPG + (pl >> LTW), px = pl & (TW - 1);
+    xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
+  }
+
+  // ---- epilogue addressing and operand prefetch state ----
+  // A convolution either masks its output by an activation derivative (data gradients inside
+  // a chain) or adds residuals (block outputs), in practice never both: each of the two
+  // common forms prefetches all its epilogue operands in one burst while the last chunk is
+  // being multiplied; the combination takes the plain path after the loop.
+  const long plane_out = (long)p.OH * p.OW * 8;
+  const bool all_octs = (nbw0 + NB) * 4 <= p.cout8;
+  const bool fast_mask = all_octs && p.mask && !p.res1 && !p.res2 && !p.ps;
+  const bool fast_res = all_octs && !p.mask && p.res1 && !p.ps;
+  typedef typename Oct<T>::vec oct_t;
+  long eoff[RW];                       // element offset of (octet plane 0, this lane's pixel); -1: outside
+#pragma unroll
+  for (int rg = 0; rg < RW; ++rg) {
+    const int g = pg * RW + rg;
+    const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
+    eoff[rg] = (oy < p.OH && ox < p.OW) ? ((long)oy * p.OW + ox) * 8 : -1;
+  }
+  oct_t pre_a[RW][NB][2];              // mask or res1; re-used for res2
+  auto prefetch = [&](const T* base_a) {
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oct = (nbw0 + n) * 4 + 2 * j + hh;
+          if (eoff[rg] < 0 || oct >= p.cout8) continue;
+          const long off = (long)oct * plane_out + eoff[rg];
+          pre_a[rg][n][j] = *reinterpret_cast<const oct_t*>(base_a + off);
+        }
   };
 
   f32x16 acc[RW][NB];
@@ -172,20 +246,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[r][n][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[r][n][i] = p.bias ? bias_v[n][i >> 2][i & 3] : 0.f;
 
-  // LDS slot (in octets) of this lane's pixel for row group rg at tap (0,0)
-  int xslot[RW];
-#pragma unroll
-  for (int rg = 0; rg < RW; ++rg) {
-    int g = wave * RW + rg;
-    int py = g * RPG + (pl >> LTW), px = pl & (TW - 1);
-    xslot[rg] = hh * NPIX + py * STRIDE * IW + px * STRIDE;
-  }
-
-#pragma unroll
-  for (int j = 0; j < DIST; ++j)
-    if (j < p.nchunk) issue(j, j);
   int stage = 0;
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
     // this chunk's DMA has landed (the DIST-1 younger chunks may stay in flight) ...
@@ -195,6 +257,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // ... in every wave; and every wave is done with the previous stage
     if (chunk + DIST < p.nchunk) issue(chunk + DIST, stage == 0 ? NSTG - 1 : stage - 1);
+    if (chunk + 1 == p.nchunk && (fast_mask || fast_res))   // this chunk waited for vmcnt(0): nothing counts after it
+      prefetch(reinterpret_cast<const T*>(fast_mask ? p.mask : p.res1) + (long)b * (fast_mask ? p.m_is : p.r1_is));
     const frag_t* sx = reinterpret_cast<const frag_t*>(smem + stage * STAGE);
     const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
     // Fragment reads run one tap ROW (KS taps) ahead of the MFMAs that consume them: with one
@@ -205,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
       for (int dx = 0; dx < KS; ++dx) {
         const int tap = dy * KS + dx;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) wf[buf][dx][n] = sw[((n * TAPS + tap) * 2 + hh) * 32 + pl];
+        for (int n = 0; n < NB; ++n) wf[buf][dx][n] = sw[(((bg * NB + n) * TAPS + tap) * 2 + hh) * 32 + pl];
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
       }
@@ -227,97 +291,169 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
   }
 
   // ---- epilogue ----
-  const long plane_out = (long)p.OH * p.OW * 8;
+  // One wave per SIMD issues an instruction every few cycles, so this straight-line tail is
+  // priced by its instruction count: every run-time option is tested ONCE per wave (uniform
+  // branches around whole passes over the accumulators), never per stored octet.
+  const bool full = (nbw0 + NB) * 4 <= p.cout8 || p.ps;        // every octet of these blocks exists
+  const bool fast = full && !(p.mask && !fast_mask) && !((p.res1 || p.res2) && !fast_res);
+  if (fast) {
+    if (fast_mask) {
+      const float ms = p.mask_slope;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[rg][n][i] = (float)pre_a[rg][n][i >> 3][i & 7] > 0.f ? acc[rg][n][i] : acc[rg][n][i] * ms;
+    }
+    if (p.act_slope != 1.f) {          // LeakyReLU / ReLU, slope in [0,1): max(v, slope*v)
+      const float as = p.act_slope;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[rg][n][i] = (as >= 0.f && as <= 1.f) ? fmaxf(acc[rg][n][i], acc[rg][n][i] * as)
+                                                     : (acc[rg][n][i] > 0.f ? acc[rg][n][i] : acc[rg][n][i] * as);
+    }
+    if (p.alpha != 1.f) {
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[rg][n] *= p.alpha;
+    }
+    if (fast_res) {
+      const float b1 = p.beta1;
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rg][n][i] += b1 * (float)pre_a[rg][n][i >> 3][i & 7];
+      if (p.res2) {                    // second residual: one more burst into the same registers
+        prefetch(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is);
+        const float b2 = p.beta2;
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rg][n][i] += b2 * (float)pre_a[rg][n][i >> 3][i & 7];
+      }
+    }
+    T* yb = reinterpret_cast<T*>(p.y) + (long)b * p.y_is;
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg) {
+      if (eoff[rg] < 0) continue;
+      T* yrow;
+      long ostep;                      // element step between consecutive stored octets (j, then n)
+      if (p.ps) {                      // PixelShuffle(2): sub-pixel (hh, j) of output channel block nb
+        const int g = pg * RW + rg;
+        const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
+        yrow = yb + (long)nbw0 * 4 * plane_out + ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox) * 8;
+        ostep = 8;
+      } else {
+        yrow = yb + (long)(nbw0 * 4 + hh) * plane_out + eoff[rg];
+        ostep = 2 * plane_out;
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
+          store_oct(yrow + (p.ps ? (long)n * 4 * plane_out + j * ostep : (long)(n * 2 + j) * ostep), v);
+        }
+    }
+    return;
+  }
+  // general form (ragged channel counts, mask together with residuals): per stored octet
 #pragma unroll
   for (int rg = 0; rg < RW; ++rg) {
-    const int g = wave * RW + rg;
-    const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
-    if (oy >= p.OH || ox >= p.OW) continue;
+    if (eoff[rg] < 0) continue;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int nb = nb0 + n;
+      const int nb = nbw0 + n;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        const int oct = nb * 4 + 2 * j + hh;
+        if (oct >= p.cout8) continue;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
-        if (p.bias) {
-          const float* bp = p.bias + (nb * 2 + hh) * 16 + j * 8;
-          f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
-          f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        const long off = (long)oct * plane_out + eoff[rg];
+        if (p.mask) {
+          float m[8];
+          load_oct(reinterpret_cast<const T*>(p.mask) + (long)b * p.m_is + off, m);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
         }
-        if (p.ps) {
-          if (nb >= p.cout8) continue;
-          T* yp = reinterpret_cast<T*>(p.y) + (long)b * p.y_is + (long)nb * 4 * plane_out +
-                  ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox + j) * 8;
-          if (p.act_slope != 1.f) {
+        if (p.act_slope != 1.f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
-          }
-          store_oct(yp, v);
-        } else {
-          const int oct = nb * 4 + 2 * j + hh;
-          if (oct >= p.cout8) continue;
-          const long off = (long)oct * plane_out + ((long)oy * p.OW + ox) * 8;
-          if (p.mask) {
-            float m[8];
-            load_oct(reinterpret_cast<const T*>(p.mask) + (long)b * p.m_is + off, m);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
-          }
-          if (p.act_slope != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
-          }
-          if (p.alpha != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-          }
-          if (p.res1) {
-            float r[8];
-            load_oct(reinterpret_cast<const T*>(p.res1) + (long)b * p.r1_is + off, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.beta1 * r[e];
-          }
-          if (p.res2) {
-            float r[8];
-            load_oct(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is + off, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.beta2 * r[e];
-          }
-          store_oct(reinterpret_cast<T*>(p.y) + (long)b * p.y_is + off, v);
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
         }
+        if (p.alpha != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        }
+        if (p.res1) {
+          float r[8];
+          load_oct(reinterpret_cast<const T*>(p.res1) + (long)b * p.r1_is + off, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.beta1 * r[e];
+        }
+        if (p.res2) {
+          float r[8];
+          load_oct(reinterpret_cast<const T*>(p.res2) + (long)b * p.r2_is + off, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.beta2 * r[e];
+        }
+        store_oct(reinterpret_cast<T*>(p.y) + (long)b * p.y_is + off, v);
       }
     }
   }
 }
 
-template <typename T, int STRIDE, int NB, int RW, int LTW, int KS>
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS, int WAVES = 4, int CW = 1>
 int launch(const ConvParams& p0, int B, hipStream_t stream) {
+  constexpr int THREADS = 64 * WAVES;
   constexpr int TW = 1 << LTW;
-  constexpr int TH = 4 * RW * (32 >> LTW);
+  constexpr int TH = (WAVES / CW) * RW * (32 >> LTW);
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
   constexpr int PPO = Oct<T>::PPO;
-  constexpr int XPP = ((2 * IH * IW * PPO + 255) / 256) * 256, WPP = ((NB * KS * KS * 64 * PPO + 255) / 256) * 256;
-  constexpr int LDS = RingDepth<T, STRIDE, NB, RW, LTW, KS>::value * (XPP + WPP) * 16;
+  constexpr int XPP = ((2 * IH * IW * PPO + THREADS - 1) / THREADS) * THREADS;
+  constexpr int WPP = ((NB * CW * KS * KS * 64 * PPO + THREADS - 1) / THREADS) * THREADS;
+  constexpr int LDS = RingDepth<T, NB, RW, WAVES, CW>::value * (XPP + WPP) * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvParams p = p0;
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + TH - 1) / TH;
-  p.ngroups = p.nblk / NB;
-  auto kern = conv_kernel<T, STRIDE, NB, RW, LTW, KS>;
+  p.ngroups = p.nblk / (NB * CW);
+  auto kern = conv_kernel<T, STRIDE, NB, RW, LTW, KS, WAVES, CW>;
   static bool attr_set = false;
   if (!attr_set) {
     SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  long grid = (long)p.tiles_x * p.tiles_y * B * p.ngroups;
-  SRX_CHECK_ARG(grid > 0 && grid < (1L << 31), "conv grid out of range");
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+  const long gx = (long)p.tiles_x * p.ngroups;
+  SRX_CHECK_ARG(gx > 0 && gx < (1L << 31) && p.tiles_y > 0 && p.tiles_y <= 65535 && B <= 65535,
+                "conv grid out of range (%ld x %d x %d)", gx, p.tiles_y, B);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)p.tiles_y, (unsigned)B), dim3(THREADS), LDS, stream, p);
   return srx_check_launch("conv_kernel");
+}
+
+// SRX_CONV_WAVES=8 selects the eight-wave workgroup shape for the 32-wide bf16 3x3 stride-1 tiles (tuning).
+static int forced_waves() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SRX_CONV_WAVES");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 template <typename T>
@@ -328,6 +464,13 @@ int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
   }
   if (d->stride == 1) {
     if (p.OW >= 24) {
+      if constexpr (sizeof(T) == 2) {
+        // Eight waves per workgroup (two per SIMD) on the same 32x8 tile: measured no faster per
+        // 16-channel chunk than four (the loop is bound by the L2 -> LDS staging rate, not by
+        // issue), and slower next to a co-resident weight-gradient workgroup; kept selectable.
+        if (forced_waves() == 8)
+          return nb2 ? launch<T, 1, 1, 2, 5, 3, 8, 2>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3, 8, 1>(p, d->B, s);
+      }
       if (p.OH * p.OW >= 128 * 128 && !nb2) return launch<T, 1, 1, 4, 5, 3>(p, d->B, s);
       return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
     }

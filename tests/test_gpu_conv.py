@@ -76,3 +76,17 @@ def test_pixel_shuffle_indexing_bit_exact():
     # and the oracle's index formula equals the reference's nn.PixelShuffle output (golden)
     xg = torch.arange(2 * 8 * 3 * 5, dtype=torch.float32).reshape(2, 8, 3, 5)
     assert np.array_equal(O.pixel_shuffle2(xg).numpy().astype(np.int32), arr["pixel_shuffle_out"])
+
+
+def test_eight_wave_workgroup_shape_matches(tmp_path):
+    """The eight-wave tile shapes (selected with SRX_CONV_WAVES=8, read once per process) give the
+    same results as the default four-wave ones: run the generator block tests in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SRX_CONV_WAVES="8")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_generator.py"), "-k", "blocks_match or generator_1block"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
