@@ -185,7 +185,7 @@ void conv_kernel(const ConvParams p) {
     int piece = tid + i * THREADS;
     int nb = piece / (TAPS * 64 * PPO);
     int rem = piece % (TAPS * 64 * PPO);
-    woff[i] = piece < WP ? (unsigned)nb * p.nchunk * wchunk_bytes + (unsigned)rem * 16u : OOB;
+    woff[i] = piece < 0 ? (unsigned)nb * p.nchunk * wchunk_bytes + (unsigned)rem * 16u : OOB;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int chunk, int stage) {
@@ -472,9 +472,6 @@ int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
           return nb2 ? launch<T, 1, 1, 2, 5, 3, 8, 2>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3, 8, 1>(p, d->B, s);
       }
       if (p.OH * p.OW >= 128 * 128 && !nb2) return launch<T, 1, 1, 4, 5, 3>(p, d->B, s);
-      // too few 32x8 tiles to give every CU a workgroup: 32x4 tiles
-      const long wgs8 = (long)((p.OW + 31) / 32) * ((p.OH + 7) / 8) * d->B * (p.nblk / (nb2 ? 2 : 1));
-      if (wgs8 < 256) return nb2 ? launch<T, 1, 2, 1, 5, 3>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3>(p, d->B, s);
       return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
     }
     if (p.OW >= 12) return nb2 ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);

@@ -175,7 +175,7 @@ void conv_kernel(const ConvParams p) {
     int h = piece / (PPO * NPIX);
     int r = pix / IW, c = pix % IW;
     int gy = iy0 + r, gx = ix0 + c;
-    bool ok = piece < XP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    bool ok = piece < 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     // out-of-image slots stay out of range for every chunk: OOB minus the largest chunk offset
     xoff[i] = ok ? (unsigned)h * plane_bytes + (unsigned)(((gy * p.W + gx) * 8 + q * EPP) * (int)sizeof(T))
                  : OOB;
@@ -472,9 +472,6 @@ int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
           return nb2 ? launch<T, 1, 1, 2, 5, 3, 8, 2>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3, 8, 1>(p, d->B, s);
       }
       if (p.OH * p.OW >= 128 * 128 && !nb2) return launch<T, 1, 1, 4, 5, 3>(p, d->B, s);
-      // too few 32x8 tiles to give every CU a workgroup: 32x4 tiles
-      const long wgs8 = (long)((p.OW + 31) / 32) * ((p.OH + 7) / 8) * d->B * (p.nblk / (nb2 ? 2 : 1));
-      if (wgs8 < 256) return nb2 ? launch<T, 1, 2, 1, 5, 3>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3>(p, d->B, s);
       return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
     }
     if (p.OW >= 12) return nb2 ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);

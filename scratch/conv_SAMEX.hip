@@ -131,10 +131,10 @@ void conv_kernel(const ConvParams p) {
   const int nb0 = grp * (NB * CW);          // first block staged by the workgroup
   const int nbw0 = nb0 + bg * NB;           // first block of this wave
   const int oy0 = ty * TH, ox0 = tx * TW;
-  const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+  const int iy0 = -PAD, ix0 = -PAD;
   const long plane_in = (long)p.H * p.W * 8;
 
-  const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
+  const T* xb = reinterpret_cast<const T*>(p.x);
   const T* wb = reinterpret_cast<const T*>(p.w);
 
   // The bias is the accumulators' initial value: a lane's 16 accumulator registers of block n
@@ -472,9 +472,6 @@ int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
           return nb2 ? launch<T, 1, 1, 2, 5, 3, 8, 2>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3, 8, 1>(p, d->B, s);
       }
       if (p.OH * p.OW >= 128 * 128 && !nb2) return launch<T, 1, 1, 4, 5, 3>(p, d->B, s);
-      // too few 32x8 tiles to give every CU a workgroup: 32x4 tiles
-      const long wgs8 = (long)((p.OW + 31) / 32) * ((p.OH + 7) / 8) * d->B * (p.nblk / (nb2 ? 2 : 1));
-      if (wgs8 < 256) return nb2 ? launch<T, 1, 2, 1, 5, 3>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3>(p, d->B, s);
       return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
     }
     if (p.OW >= 12) return nb2 ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);

@@ -78,7 +78,7 @@ class OpList(list):
         self.meta: List[Tuple[str, float]] = []
 
 
-def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: int) -> str:
+def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: int, B: int = 1 << 20) -> str:
     """Mirror of the instantiation choice in csrc/conv.hip (dispatch<T>)."""
     t = "bf16" if dt == L.BF16 else "float"
     nb = 2 if (_ceil(cout, 32) % 2 == 0) else 1
@@ -86,7 +86,8 @@ def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: i
         cfg = (1, nb, 1, 5, 1)
     elif stride == 1:
         if OW >= 24:
-            cfg = (1, 1, 4, 5, 3) if (OH * OW >= 128 * 128 and nb == 1) else (1, nb, 2, 5, 3)
+            wgs8 = _ceil(OW, 32) * _ceil(OH, 8) * B * (_ceil(cout, 32) // nb)
+            cfg = (1, 1, 4, 5, 3) if (OH * OW >= 128 * 128 and nb == 1) else (1, nb, 1 if wgs8 < 256 else 2, 5, 3)
         elif OW >= 12:
             cfg = (1, nb, 1, 4, 3)
         else:
@@ -213,7 +214,7 @@ class Plan:
         if isinstance(ops, OpList):
             pad = ksize // 2
             OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
-            ops.meta.append((conv_kernel_name(self.dt, ksize, stride, OH, OW, cout),
+            ops.meta.append((conv_kernel_name(self.dt, ksize, stride, OH, OW, cout, B),
                              2.0 * B * OH * OW * ksize * ksize * cin * cout))
 
     def generic(self, ops: list, kind: int, *, a: Optional[View] = None, b: Optional[View] = None,
