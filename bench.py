@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--wgrad-overlap", type=int, default=1, help="weight gradients on a side stream (0/1)")
+    ap.add_argument("--skip-wgrad", action="store_true", help="diagnostic: drop weight-gradient launches (INVALID as a result)")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     args = ap.parse_args()
 
@@ -132,6 +133,8 @@ def main():
     adv = args.workload == "c3"
     B, h = args.batch, args.patch or (32 if adv else 64)
     sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0) if world > 1 else None
+    if args.skip_wgrad:
+        E.Plan.wgrad = lambda self, ops, *a, **k: None
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
     if args.wgrad_rdbs is not None:
         E.GeneratorPlan.trunk_wgrad_rdbs = args.wgrad_rdbs
@@ -180,7 +183,7 @@ def main():
         "metric": "LR Mpixels/sec ESRGAN 4x train step (fwd+bwd)", "value": round(value, 4),
         "unit": "LR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic" if not args.skip_wgrad else "INVALID: weight gradients skipped",
         "config": {"workload": (f"config 3: adversarial step (D step + G step, 3 discriminator forwards, spectral "
                                 f"norm, VGG loss, Adam on both), batch {B}/GPU of {h}x{h} LR patches, bf16") if adv
                                else (f"config 2: 23-RRDB generator warm-up (L1), fwd+bwd+Adam, batch {B}/GPU "

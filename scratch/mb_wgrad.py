@@ -1,0 +1,26 @@
+import ctypes, importlib, sys, torch
+sys.path.insert(0, '.')
+L = importlib.import_module("super-resolution_amd._lib")
+if len(sys.argv) > 1 and sys.argv[1] != "base":
+    L.LIB_PATH = "scratch/libsrx_%s.so" % sys.argv[1]
+E = importlib.import_module("super-resolution_amd.engine")
+G = importlib.import_module("super-resolution_amd.esrgan.generator")
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+gen = G.GeneratorESRGAN(num_blocks=23).to(dev)
+params = {n: p.data for n, p in gen.named_parameters()}
+plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, need_grad=True)
+x = torch.rand(16, 3, 64, 64, device=dev) * 2 - 1
+plan.forward(x)
+plan.GY.t.normal_()
+plan.run(plan.bwd_ops); torch.cuda.synchronize()
+idx = [i for i, (n, f) in enumerate(plan.bwd_meta) if n.startswith("wgrad_kernel") and f > 1e11]
+ops = (L.Op * len(idx))(*[plan.bwd_ops[i] for i in idx])
+fl = sum(plan.bwd_meta[i][1] for i in idx)
+plan.run(ops); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): plan.run(ops)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(sys.argv[1:], f"{len(idx)} trunk wgrad launches: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")

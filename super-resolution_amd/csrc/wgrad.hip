@@ -58,6 +58,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_base, int addr0, int a
 
 constexpr int pad4mod8(int n) { return n + ((4 - n % 8) + 8) % 8; }
 
+// LDS-DMA issued as inline assembly.  With the compiler's own builtin, its wait-count pass
+// treats every later ds_read_b64_tr_b16 as possibly reading what the DMA writes and puts an
+// s_waitcnt vmcnt(0) in front of the first one: the next tile's staging would then complete
+// before this tile's multiply starts, i.e. no overlap at all.  The ring protocol (which stage is
+// written, which is read, the explicit vmcnt(0) + barrier at the end of a tile) carries the
+// ordering instead.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long a = (unsigned long)base;
+  u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+// 16 bytes per lane from rsrc + voffset (out of range: zeros) to LDS byte address lds_addr + 16*lane;
+// lds_addr must be wave-uniform.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory", "m0");
+}
+
 // Stage one tile (X halo tile + GY tile) into LDS stage `ls` by LDS-DMA.  A free function
 // rather than a lambda: hipcc (ROCm 7.2) drops the host-side kernel stub when a by-reference
 // captured array feeds this builtin's offset operand.
@@ -79,28 +98,25 @@ __device__ __forceinline__ void wgrad_stage_tile(const WgradParams& p, const T* 
     // border tiles: those lanes are out of range by construction and never dereferenced)
     const long xoff_b = ((long)iy0 * p.W + ix0) * 8 * (long)sizeof(T);
     const long goff_b = ((long)oy0 * p.OW + ox0) * 8 * (long)sizeof(T);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(xbase + (long)b * p.x_is) + xoff_b), 0,
-        (int)(xbytes - xoff_b), 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(gbase + (long)b * p.gy_is) + goff_b), 0,
-        (int)(gbytes - goff_b), 0x00020000);
+    const u32x4 xrs = make_rsrc(reinterpret_cast<const char*>(xbase + (long)b * p.x_is) + xoff_b,
+                                (unsigned)(xbytes - xoff_b));
+    const u32x4 grs = make_rsrc(reinterpret_cast<const char*>(gbase + (long)b * p.gy_is) + goff_b,
+                                (unsigned)(gbytes - goff_b));
+    const unsigned lds0 = (unsigned)(unsigned long)ls;      // low 32 bits of a flat LDS address = LDS offset
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       const unsigned gy_ = (unsigned)(iy0 + (xrc[i] & 0xffff)), gx_ = (unsigned)(ix0 + (xrc[i] >> 16));
       const bool ok = xrc[i] >= 0 && gy_ < (unsigned)p.H && gx_ < (unsigned)p.W;
       if (NXS * 256 == XSL || tid + i * 256 < XSL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(ls + (i * 256 + wave_u * 64) * 16), 16,
-                                                 ok ? xoffs[i] : OOB, 0, 0, 0);
+        lds_dma16(xrs, lds0 + (i * 256 + wave_u * 64) * 16, ok ? xoffs[i] : OOB);
     }
-    char* lg = ls + XSL * 16;
+    const unsigned lg0 = lds0 + XSL * 16;
 #pragma unroll
     for (int i = 0; i < NGS; ++i) {
       const unsigned oy = (unsigned)(oy0 + (grc[i] & 0xffff)), ox = (unsigned)(ox0 + (grc[i] >> 16));
       const bool ok = grc[i] >= 0 && oy < (unsigned)p.OH && ox < (unsigned)p.OW;
       if (NGS * 256 == GSL || tid + i * 256 < GSL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(lg + (i * 256 + wave_u * 64) * 16), 16,
-                                                 ok ? goffs[i] : OOB, 0, 0, 0);
+        lds_dma16(grs, lg0 + (i * 256 + wave_u * 64) * 16, ok ? goffs[i] : OOB);
     }
   }
 
@@ -269,7 +285,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   int tile = t_begin;
   if (tile < t_end) stage_tile(tile, 0);
-  __syncthreads();            // (the compiler drains the DMA, vmcnt(0), ahead of the barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   int stage = 0;
   for (; tile < t_end; ++tile) {
     const bool more = tile + 1 < t_end;
@@ -323,7 +340,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
       }
     }
-    __syncthreads();
+    // the next tile has landed (every wave's share of it) and every wave is done reading this one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     stage ^= 1;
   }
 
