@@ -200,8 +200,20 @@ def main():
         tot = sum(v[0] for v in stats.values())
         name, (ms, flops, n) = max(stats.items(), key=lambda kv: kv[1][0])
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes over this
+        # same command (counters cannot be read from inside the process); the summary is kept
+        # under profiles/ with the command that produced it
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                k = json.load(f)["kernels"].get(name)
+            if k and not adv and (B, h, args.blocks) == (16, 64, 23):
+                traffic = k["fetch_bytes"] + k["write_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
                            "launches": n, "avg_us": round(ms * 1e3 / n, 2),
                            "share_of_step_kernel_time": round(ms / tot, 3)}
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0]
