@@ -9,6 +9,9 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 gen = G.GeneratorESRGAN(num_blocks=23).to(dev)
 params = {n: p.data for n, p in gen.named_parameters()}
+import os
+E.GeneratorPlan.trunk_wgrad_slices = int(os.environ.get('SLICES', '4'))
+E.GeneratorPlan.trunk_wgrad_rdbs = int(os.environ.get('RDBS', '6'))
 plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, need_grad=True)
 x = torch.rand(16, 3, 64, 64, device=dev) * 2 - 1
 plan.forward(x)
