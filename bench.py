@@ -189,7 +189,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic" if not args.skip_wgrad else "INVALID: weight gradients skipped",
         "config": {"workload": (f"config 3: adversarial step (D step + G step, 3 discriminator forwards, spectral "
                                 f"norm, VGG loss, Adam on both), batch {B}/GPU of {h}x{h} LR patches, bf16") if adv
-                               else (f"config 2: 23-RRDB generator warm-up (L1), fwd+bwd+Adam, batch {B}/GPU "
+                               else ({(16, 64): "config 2", (64, 128): "config 5 shape"}.get((B, h), "custom shape") +
+                                     f": 23-RRDB generator warm-up (L1), fwd+bwd+Adam, batch {B}/GPU "
                                      f"of {h}x{h} LR patches, bf16") if args.blocks == 23 else
                                f"{args.blocks}-RRDB generator warm-up, batch {B}, {h}x{h}",
                    "global_batch": world * B, "lr_patch": h, "parallelism": f"dp{world}",

@@ -23,3 +23,28 @@ for tag in ("E, 1, 2, 5, 3>", "E, 2, 2, 5, 3>"):
         len(a), sum(a) / max(len(a), 1) / 1e3, len(b), sum(b) / max(len(b), 1) / 1e3))
 # busy union
 ev = sorted([(s, 1) for s, e, k, q in step] + [(e, -1) for s, e, k, q in step])
+def first(pred):
+    for s, e, k, q in step:
+        if pred(k):
+            return (s - t0) / 1e6, (e - t0) / 1e6
+    return None
+def last(pred):
+    r = None
+    for s, e, k, q in step:
+        if pred(k):
+            r = ((s - t0) / 1e6, (e - t0) / 1e6)
+    return r
+print("pack      ", first(lambda k: "pack_kernel" in k))
+print("loss (end of forward)", first(lambda k: "pix_loss" in k))
+print("last conv ", last(lambda k: "conv_kernel" in k))
+print("last wgrad", last(lambda k: "wgrad_kernel" in k))
+print("unpack    ", last(lambda k: "unpack" in k))
+print("adam      ", last(lambda k: "adam" in k))
+tot = {}
+for s, e, k, q in step:
+    import re
+    m = re.search(r"(conv_kernel|wgrad_kernel)<[^>]*>", k)
+    kk = m.group(0) if m else k.split("(")[0][-40:]
+    tot.setdefault(kk, [0, 0]); tot[kk][0] += e - s; tot[kk][1] += 1
+for kk, (t, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:8]:
+    print(f"{t/1e6:8.3f} ms {n:5d} x {t/n/1e3:8.2f} us  {kk}")
