@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--wgrad-overlap", type=int, default=1, help="weight gradients on a side stream (0/1)")
     ap.add_argument("--skip-wgrad", action="store_true", help="diagnostic: drop weight-gradient launches (INVALID as a result)")
+    ap.add_argument("--graphs", type=int, default=0, help="replay recorded op lists as HIP graphs (0/1)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     args = ap.parse_args()
@@ -136,6 +137,7 @@ def main():
     sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0) if world > 1 else None
     if args.skip_wgrad:
         E.Plan.wgrad = lambda self, ops, *a, **k: None
+    E.Plan.use_graphs = bool(args.graphs)
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
     if args.wgrad_slices is not None:
         E.GeneratorPlan.trunk_wgrad_slices = args.wgrad_slices

@@ -333,6 +333,15 @@ typedef struct srx_op {
 /* Launch a recorded sequence of ops back to back on one stream with a single
  * crossing of the language boundary (a whole generator forward or backward). */
 int srx_run_ops(const srx_op* ops, int n, void* stream);
+/* The same sequence captured once as a HIP graph and replayed with one call: a host launch
+ * costs ~3.5 us, so chains of short kernels (small patches, tiled inference) are otherwise
+ * bound by the host.  Every op of the list must have run once through srx_run_ops before
+ * (kernels set their attributes on first use); descriptors and the memory they point at must
+ * stay as they were at capture.  The graph objects are the only thing libsrx ever allocates;
+ * destroy them with srx_graph_destroy. */
+int srx_graph_capture(const srx_op* ops, int n, void** graph_exec);
+int srx_graph_launch(void* graph_exec, void* stream);
+int srx_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus
 }

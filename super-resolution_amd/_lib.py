@@ -129,6 +129,9 @@ _SIGS = {
     "srx_sn_backward": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "srx_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
     "srx_run_ops": (C.c_int, [vp, C.c_int, vp]),
+    "srx_graph_capture": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "srx_graph_launch": (C.c_int, [vp, vp]),
+    "srx_graph_destroy": (C.c_int, [vp]),
     "srx_tile_gather": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
     "srx_crop_augment": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "srx_tile_blend": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,

@@ -359,11 +359,40 @@ class Plan:
     def freeze(ops: list):
         return (L.Op * len(ops))(*ops) if ops else None
 
+    # Replay recorded op lists as HIP graphs from their second run on.  Off by default: measured on
+    # MI355X / ROCm 7.2 a replay keeps the same ~2-4 us between short kernels as plain launches
+    # (config 3: 12.8 vs 12.95 ms/step), so it buys nothing here.
+    use_graphs = False
+    _GRAPH_MIN_OPS = 8
+
     def run(self, frozen, stream: Optional[torch.cuda.Stream] = None) -> None:
         if frozen is None:
             return
         sp = stream.cuda_stream if stream is not None else stream_ptr(self.device)
-        L.check(self.lib.srx_run_ops(C.addressof(frozen), len(frozen), sp), "srx_run_ops")
+        n = len(frozen)
+        if self.use_graphs and n >= self._GRAPH_MIN_OPS:
+            graphs = self.__dict__.setdefault("_graphs", {})
+            key = C.addressof(frozen)
+            g = graphs.get(key)
+            if g is None:
+                # first run: plain launches (kernels set their attributes on first use)
+                graphs[key] = 0
+            elif g == 0:
+                ex = C.c_void_p()
+                L.check(self.lib.srx_graph_capture(key, n, C.byref(ex)), "srx_graph_capture")
+                graphs[key] = g = (ex, frozen)          # keeps the descriptor array alive
+            if g:
+                L.check(self.lib.srx_graph_launch(g[0], sp), "srx_graph_launch")
+                return
+        L.check(self.lib.srx_run_ops(C.addressof(frozen), n, sp), "srx_run_ops")
+
+    def __del__(self):
+        try:
+            for g in self.__dict__.get("_graphs", {}).values():
+                if g:
+                    self.lib.srx_graph_destroy(g[0])
+        except Exception:
+            pass
 
     # ------------------------------------------------- two-stream op lists
     # Weight-gradient launches depend only on tensors the data-gradient chain has already

@@ -100,3 +100,51 @@ def test_generator_23_bf16_forward_close():
     samp = out.flatten()[::7].cpu()
     ref = torch.from_numpy(arr["g23_out_s7"])
     assert rel_l2(samp, ref) < 2e-2
+
+
+def test_graph_replay_matches_plain_launches():
+    """A plan replayed through srx_graph_capture / srx_graph_launch gives the results of plain
+    launches (third run on: first run plain, second captures)."""
+    E = pkg("engine")
+    G = pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=3).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    x = O.hash_input("graph.x", (2, 3, 16, 16)).cuda()
+    gy = O.hash_input("graph.gy", (2, 3, 64, 64)).cuda()
+    outs = []
+    for use in (False, True):
+        plan = E.GeneratorPlan(params, 2, 16, 16, torch.float32, num_blocks=2, need_grad=True)
+        plan.use_graphs = use
+        for _ in range(3):
+            y = plan.forward(x)
+            plan.backward(gy)
+        torch.cuda.synchronize()
+        if use:
+            assert any(v for v in plan._graphs.values()), "no graph was captured"
+        outs.append((y.clone(), plan.flat_grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-4          # weight gradients accumulate with atomics
+
+
+def test_config2_full_size_homogeneity_and_determinism():
+    """Size-independent properties at the benchmark's full size (B=16, 64x64 LR, 23 blocks, bf16):
+    with zero biases the generator is positively homogeneous (LeakyReLU and the residual
+    scalings commute with a power-of-two scale, and so does bf16 rounding), so G(2x) == 2 G(x)
+    bit for bit; and the forward is deterministic."""
+    E = pkg("engine")
+    G = pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=23), salt=13).cuda()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith(".bias"):
+                p.zero_()
+    params = {n: p.data for n, p in g.named_parameters()}
+    plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, num_blocks=23, need_grad=False)
+    x = (O.hash_input("c2.x", (16, 3, 64, 64)) * 0.5).cuda()
+    y1 = plan.forward(x).clone()
+    y1b = plan.forward(x).clone()
+    y2 = plan.forward(2 * x).clone()
+    assert y1.shape == (16, 3, 256, 256)
+    assert torch.isfinite(y1).all() and float(y1.abs().max()) > 0
+    assert torch.equal(y1, y1b)
+    assert torch.equal(y2, 2 * y1)
