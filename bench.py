@@ -92,13 +92,47 @@ def cpu_baseline(iters=3):
                       f"{iters} timed iters after 1 warm-up, {dt:.3f} s/iter"}
 
 
+def bench_inference(args, dev, rank, world):
+    """Config 4: generator forward only, bf16, replicas (no collective): B images of patch x patch
+    LR per GPU (default 4 of 512x512 = the 8-GPU share of 32 images), whole-image or tiled."""
+    I = importlib.import_module("super-resolution_amd.inference")
+    G = importlib.import_module("super-resolution_amd.esrgan.generator")
+    torch.manual_seed(0)
+    gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
+    B = args.batch if args.batch != 16 else 4
+    h = args.patch or 512
+    eng = I.SuperResolutionInference("esrgan", model=gen, half_precision=True, device=str(dev), window="hann_pos")
+    x = torch.rand((B, 3, h, h), generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    for _ in range(max(1, args.warmup // 2)):
+        eng.upscale(x, tile_size=args.tile)
+    torch.cuda.synchronize()
+    steps = max(1, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.upscale(x, tile_size=args.tile)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    value = world * B * h * h / dt / 1e6
+    out = {"metric": "LR Mpixels/sec ESRGAN 4x inference forward", "value": round(value, 3), "unit": "LR Mpixels/s",
+           "n_gpus": world, "steps": steps, "warmup": max(1, args.warmup // 2), "ms_per_step": round(dt * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"config 4: inference, {B} images/GPU of {h}x{h} LR -> {4 * h}x{4 * h}, "
+                                  + (f"tiled {args.tile}/overlap 32, tiles batched" if args.tile else "whole image"),
+                      "parallelism": f"replicas x{world}"},
+           "algorithmic_tflops": round(value * 1e6 * 35_853_696 / 1e12, 1) if args.blocks == 23 else None}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2: generator warm-up step (the headline); c3: full adversarial D+G step")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2: generator warm-up step (the headline); c3: full adversarial D+G step; "
+                         "c4: inference forward (whole image, or tiled with --tile)")
+    ap.add_argument("--tile", type=int, default=0, help="c4: tile size (0 = whole image), overlap 32")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--patch", type=int, default=None, help="LR patch size (default 64 for c2, 32 for c3)")
     ap.add_argument("--blocks", type=int, default=23)
@@ -132,6 +166,8 @@ def main():
 
     torch.manual_seed(0)
     gen = G.GeneratorESRGAN(num_blocks=args.blocks).to(dev)
+    if args.workload == "c4":
+        return bench_inference(args, dev, rank, world)
     adv = args.workload == "c3"
     B, h = args.batch, args.patch or (32 if adv else 64)
     sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0) if world > 1 else None
