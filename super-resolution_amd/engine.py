@@ -773,7 +773,23 @@ class GeneratorPlan(_GenBase):
         # Dense blocks, last to first.  Their weight gradients go out in launches of several
         # blocks each: long-running workgroups, few pixel slices (little atomic traffic), block
         # order keeps one block's buffers hot in L2.
-        per_launch = self.trunk_wgrad_rdbs if (self.overlap_wgrad and self.trunk_wgrad_rdbs > 0) else nR
+        # launch sizes (dense blocks per launch), in backward order.  The last launches run after
+        # the data-gradient chain has ended, with nothing to hide behind: they shrink (and take
+        # more pixel slices, below) so that this tail is short.
+        if self.overlap_wgrad and self.trunk_wgrad_rdbs > 0:
+            tail = [s_ for s_ in (4, 3, 2) if s_ < self.trunk_wgrad_rdbs]
+            sizes, left = [], nR
+            while left > sum(tail) + self.trunk_wgrad_rdbs:
+                sizes.append(self.trunk_wgrad_rdbs)
+                left -= self.trunk_wgrad_rdbs
+            for s_ in [left - sum(tail)] + tail if left > sum(tail) else [left]:
+                if s_ > 0:
+                    sizes.append(s_)
+        else:
+            sizes = [nR]
+        assert sum(sizes) == nR
+        launch_sizes = iter(sizes)
+        per_launch = next(launch_sizes, nR)
         pending: list = []
         pending_names: List[str] = []
         n_pending = 0
@@ -785,7 +801,9 @@ class GeneratorPlan(_GenBase):
             tasks, nblocks, names = pending, n_pending, pending_names
             pending, pending_names, n_pending = [], [], 0
             per_block = len(tasks) // nblocks
-            aside(lambda o: self.wgrad(o, None, None, tasks, B, h, w, nslices=self.trunk_wgrad_slices,
+            # enough pixel slices to give every CU a workgroup, at least the configured number
+            nsl = max(self.trunk_wgrad_slices, min(32, 256 // max(1, len(tasks))))
+            aside(lambda o: self.wgrad(o, None, None, tasks, B, h, w, nslices=nsl,
                                        x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
                                        group=per_block if per_block * nblocks == len(tasks) else 0), names)
 
@@ -798,6 +816,7 @@ class GeneratorPlan(_GenBase):
             n_pending += 1
             if n_pending == per_launch:
                 flush()
+                per_launch = next(launch_sizes, nR)
         flush()
         # feat also feeds the trunk skip (esrgan/generator.py:68): gfeat += gT1
         self.generic(bwd, L.OP_AXPBY, a=(self.gT1, 0), c=(self.gfeat, 0), f0=1.0, f1=1.0,
