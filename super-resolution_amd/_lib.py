@@ -21,6 +21,7 @@ BF16, F32 = 0, 1
 OP_CONV, OP_WGRAD, OP_PIXEL_UNSHUFFLE, OP_CHANNEL_SUM, OP_ZERO_STUFF = 1, 2, 3, 4, 5
 OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_MEMSET, OP_AXPBY, OP_GAP_FWD, OP_GAP_BWD = 6, 7, 8, 9, 10, 11
 OP_ACT_BWD = 12
+OP_CONV_PAIR = 13
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -90,8 +91,16 @@ class Crop(C.Structure):
     _fields_ = [("img", vp), ("H", i32), ("W", i32), ("y0", i32), ("x0", i32), ("flags", i32), ("pad_", i32)]
 
 
+class ConvPairDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("cin_a", i32), ("a_out_first", i32),
+                ("x", vp), ("x_img_stride", i64), ("ya", vp), ("ya_img_stride", i64),
+                ("yb", vp), ("yb_img_stride", i64), ("wa", vp), ("wb", vp), ("bias_a", vp), ("bias_b", vp),
+                ("mask_a", vp), ("mask_a_img_stride", i64), ("mask_b", vp), ("mask_b_img_stride", i64),
+                ("mask_slope", f32), ("act_slope", f32)]
+
+
 class _OpU(C.Union):
-    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs)]
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs), ("pair", ConvPairDesc)]
 
 
 class Op(C.Structure):
@@ -107,6 +116,7 @@ _SIGS = {
     "srx_pack_weights": (C.c_int, [C.c_int, vp, vp, C.c_int, i64, vp]),
     "srx_pack_weights_scaled": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, i64, vp]),
     "srx_conv2d": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "srx_conv2d_pair": (C.c_int, [C.POINTER(ConvPairDesc), vp]),
     "srx_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
     "srx_unpack_wgrad": (C.c_int, [vp, C.c_int, i64, vp]),
     "srx_channel_sum": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
@@ -157,7 +167,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         structs = (ConvDesc, WgradTask, WgradDesc, PackSeg, PackLayer, UnpackItem, SnLayer,
-                   SnBwdLayer, GenericArgs, Op, Tile, Crop)
+                   SnBwdLayer, GenericArgs, Op, Tile, Crop, ConvPairDesc)
         for i, st in enumerate(structs):
             if l.srx_sizeof(i) != C.sizeof(st):
                 raise RuntimeError(f"libsrx ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in "

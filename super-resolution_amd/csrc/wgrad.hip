@@ -73,8 +73,12 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
 // 16 bytes per lane from rsrc + voffset (out of range: zeros) to LDS byte address lds_addr + 16*lane;
 // lds_addr must be wave-uniform.
 __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voffset) {
+  // the "s" constraint is not enforced for values the compiler holds in VGPRs: make them scalar
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+  const u32x4 r = {(unsigned)__builtin_amdgcn_readfirstlane(rsrc[0]), (unsigned)__builtin_amdgcn_readfirstlane(rsrc[1]),
+                   (unsigned)__builtin_amdgcn_readfirstlane(rsrc[2]), (unsigned)__builtin_amdgcn_readfirstlane(rsrc[3])};
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory", "m0");
+               :: "s"(a), "v"(voffset), "s"(r) : "memory");
 }
 
 // Stage one tile (X halo tile + GY tile) into LDS stage `ls` by LDS-DMA.  A free function

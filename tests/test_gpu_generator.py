@@ -148,3 +148,30 @@ def test_config2_full_size_homogeneity_and_determinism():
     assert torch.isfinite(y1).all() and float(y1.abs().max()) > 0
     assert torch.equal(y1, y1b)
     assert torch.equal(y2, 2 * y1)
+
+
+def test_generator_with_pair_convolutions_matches_separate():
+    """The dense blocks run with fused convolution pairs (opt-in) give the forward output and
+    gradients of the default one-launch-per-convolution path (bf16, 32x32 patches)."""
+    E = pkg("engine")
+    G = pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=3).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    x = O.hash_input("pair.x", (2, 3, 32, 32)).cuda()
+    gy = O.hash_input("pair.gy", (2, 3, 128, 128)).cuda() * 0.01
+    outs = []
+    for use in (False, True):
+        E.Plan.use_conv_pairs = use
+        try:
+            plan = E.GeneratorPlan(params, 2, 32, 32, torch.bfloat16, num_blocks=2, need_grad=True)
+        finally:
+            E.Plan.use_conv_pairs = False
+        names = [n for n, _ in plan.fwd_meta]
+        assert ("conv_pair_kernel<bf16>" in names) == use
+        y = plan.forward(x)
+        plan.backward(gy)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), plan.flat_grad.clone()))
+    assert rel_err(outs[1][0], outs[0][0]) < 2e-2
+    cos = torch.nn.functional.cosine_similarity(outs[1][1], outs[0][1], dim=0)
+    assert float(cos) > 0.99
