@@ -25,7 +25,16 @@ def run(nconv, B=16, H=64, W=64):
     plan.run(fr); torch.cuda.synchronize()
     buf = np.zeros(1024 * 8, dtype=np.uint64)
     assert lib.srx_dbg_stamps(buf.ctypes.data) == 0
+    cyc = np.zeros(1024 * 8, dtype=np.uint64)
+    lib.srx_dbg_cycles.argtypes = [ctypes.c_void_p]
+    assert lib.srx_dbg_cycles(cyc.ctypes.data) == 0
     nwg = B * (H // 8) * (W // 32)
+    cy = cyc.reshape(1024, 8)[:min(nwg, 1024), :].astype(np.int64)
+    rt = buf.reshape(1024, 8)[:min(nwg, 1024), :].astype(np.int64)
+    dcy, drt = cy[:, 5] - cy[:, 4], (rt[:, 5] - rt[:, 4]) * 10e-9
+    print("cycles waiting at [vmcnt + barrier], summed over chunks: median %d of loop %d" % (int(np.median(cy[:, 1])), int(np.median(dcy))))
+    print("in-loop clock (chunk0 landed -> loop done): median %.2f GHz" % float(np.median(dcy / drt) / 1e9),
+          " loop cycles median", int(np.median(dcy)), " per chunk", int(np.median(dcy)) // max(1, layers[-1][0] // 16 - 0))
     st = buf.reshape(1024, 8)[:min(nwg, 1024), :].astype(np.int64)
 
     t0 = st[:, 0].min()
@@ -39,3 +48,4 @@ def run(nconv, B=16, H=64, W=64):
     print("per-WG phase medians (ns):", [int(np.median(d[:, i])) for i in range(7)])
 for n in (1, 4):
     run(n)
+run(4, 64, 128, 128)
