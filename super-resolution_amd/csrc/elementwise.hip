@@ -433,13 +433,37 @@ __global__ void bce_logits_kernel(const T* __restrict__ logits, int n, float tar
 }
 
 // ------------------------------------------------------------ spectral norm
+// v = W^T u (un-normalised; normalised in sn_finish_kernel).  A workgroup owns 32 columns: lane
+// group g of 8 walks rows g, g+8, ... (each row access is one 128-byte segment), four loads in
+// flight per lane, then the 8 partial sums meet in LDS in a fixed order (deterministic, no atomics).
+constexpr int SN_COLS = 32;
 __global__ void sn_wt_u_kernel(const srx_sn_layer* __restrict__ layers) {
+  __shared__ float part[TPB / SN_COLS][SN_COLS];
   const srx_sn_layer L = layers[blockIdx.y];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= L.cols) return;
-  float acc = 0.f;
-  for (int r = 0; r < L.rows; ++r) acc += L.w[(long)r * L.cols + c] * L.u[r];
-  L.v[c] = acc;    // un-normalised; normalised in sn_finish_kernel
+  if ((int)blockIdx.x * SN_COLS >= L.cols) return;
+  constexpr int PH = TPB / SN_COLS;
+  const int cl = threadIdx.x % SN_COLS, ph = threadIdx.x / SN_COLS;
+  const int c = blockIdx.x * SN_COLS + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < L.cols) {
+    const float* w = L.w + c;
+    int r = ph;
+    for (; r + 3 * PH < L.rows; r += 4 * PH) {
+      a0 += w[(long)r * L.cols] * L.u[r];
+      a1 += w[(long)(r + PH) * L.cols] * L.u[r + PH];
+      a2 += w[(long)(r + 2 * PH) * L.cols] * L.u[r + 2 * PH];
+      a3 += w[(long)(r + 3 * PH) * L.cols] * L.u[r + 3 * PH];
+    }
+    for (; r < L.rows; r += PH) a0 += w[(long)r * L.cols] * L.u[r];
+  }
+  part[ph][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ph == 0 && c < L.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < PH; ++k) t += part[k][cl];
+    L.v[c] = t;
+  }
 }
 
 __device__ __forceinline__ float vec_inv_norm(const float* v, int n, float eps, float* sh) {
@@ -708,7 +732,7 @@ int srx_bce_logits(int dtype, const void* logits, int n, float target, float wei
 int srx_sn_power_iter(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols, void* stream) {
   SRX_CHECK_ARG(layers && n > 0 && max_rows > 0 && max_cols > 0, "srx_sn_power_iter: bad argument");
   if (do_pi) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + TPB - 1) / TPB, n), dim3(TPB), 0, STREAM, layers);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + SN_COLS - 1) / SN_COLS, n), dim3(TPB), 0, STREAM, layers);
     if (int rc = srx_check_launch("sn_wt_u")) return rc;
   }
   hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_rows + 3) / 4, n), dim3(TPB), 0, STREAM, layers, do_pi);
@@ -720,7 +744,7 @@ int srx_sn_power_iter(const srx_sn_layer* layers, int n, int do_pi, int max_rows
 int srx_sn_backward(const srx_sn_bwd_layer* layers, int n, int max_elems, void* stream) {
   SRX_CHECK_ARG(layers && n > 0 && max_elems > 0, "srx_sn_backward: bad argument");
   hipLaunchKernelGGL(sn_bwd_zero_kernel, dim3(1), dim3(TPB), 0, STREAM, layers, n);
-  dim3 grid(grid_for(max_elems, TPB, 64), n);
+  dim3 grid(grid_for(max_elems, TPB * 4, 512), n);
   hipLaunchKernelGGL(sn_bwd_dot_kernel, grid, dim3(TPB), 0, STREAM, layers);
   hipLaunchKernelGGL(sn_bwd_apply_kernel, grid, dim3(TPB), 0, STREAM, layers);
   return srx_check_launch("sn_backward");
