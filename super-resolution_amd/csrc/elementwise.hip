@@ -67,45 +67,69 @@ __global__ void c8_to_nchw_kernel(const T* __restrict__ src, long src_is, float*
 }
 
 // ----------------------------------------------------------------- packing
+// One (32-row block, 16-channel chunk) unit per workgroup pass: the unit's taps*512 source values are
+// read in SOURCE order (runs of 16*taps floats per output channel, or of 32*taps per input channel for
+// transposed segments), dropped into an LDS image of the packed layout, and written out as whole
+// 16/32-byte octets — both sides of the gather are coalesced.
+constexpr int PACK_PLANE = 520;   // floats per tap plane in LDS (512 + a bank offset of 8)
 template <typename T>
 __global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
                             const srx_pack_seg* __restrict__ segs,
                             const float* const* __restrict__ seg_scale_ptr) {
+  __shared__ __attribute__((aligned(16))) float tile[9 * PACK_PLANE];
   const srx_pack_layer L = layers[blockIdx.y];
   const int taps = L.taps;
-  const long nocts = (long)L.nblk * L.nchunk * taps * 64;
+  const int nunits = L.nblk * L.nchunk;
+  const int per = 512 * taps;
   T* dst = reinterpret_cast<T*>(L.dst_w);
-  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < nocts; o += (long)gridDim.x * blockDim.x) {
-    int row = (int)(o & 31);
-    int h = (int)((o >> 5) & 1);
-    long r = o >> 6;
-    int tap = (int)(r % taps); r /= taps;
-    int chunk = (int)(r % L.nchunk);
-    int nb = (int)(r / L.nchunk);
-    int n = nb * 32 + srx_row_to_chan(row, L.perm);
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = chunk * 16 + h * 8 + e;
+  const bool tr = L.seg_count > 0 && segs[L.seg_begin].transposed != 0;   // read order only
+  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const int nb = u / L.nchunk, chunk = u - nb * L.nchunk;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+      int row, cl, tsrc;
+      if (!tr) {
+        row = i / (16 * taps);
+        const int rem = i - row * 16 * taps;
+        cl = rem / taps;
+        tsrc = rem - cl * taps;
+      } else {
+        cl = i / (32 * taps);
+        const int rem = i - cl * 32 * taps;
+        row = rem / taps;
+        tsrc = rem - row * taps;
+      }
+      const int n = nb * 32 + srx_row_to_chan(row, L.perm);
+      const int c = chunk * 16 + cl;
       float val = 0.f;
+      int dtap = tsrc;
       if (n < L.cout && c < L.cin) {
-        for (int s = L.seg_begin; s < L.seg_begin + L.seg_count; ++s) {
-          const srx_pack_seg S = segs[s];
+        for (int sI = L.seg_begin; sI < L.seg_begin + L.seg_count; ++sI) {
+          const srx_pack_seg S = segs[sI];
           if (c >= S.c_begin && c < S.c_begin + S.c_count) {
             float sc = S.scale;
-            if (seg_scale_ptr && seg_scale_ptr[s]) sc *= *seg_scale_ptr[s];
-            int cc = c - S.c_begin;
-            long idx = S.transposed
-                           ? ((long)(S.src_o_off + cc) * S.cin_src + (S.src_off + n)) * taps + (taps - 1 - tap)
-                           : ((long)n * S.cin_src + (S.src_off + cc)) * taps + tap;
+            if (seg_scale_ptr && seg_scale_ptr[sI]) sc *= *seg_scale_ptr[sI];
+            const int cc = c - S.c_begin;
+            long idx;
+            if (S.transposed) {
+              idx = ((long)(S.src_o_off + cc) * S.cin_src + (S.src_off + n)) * taps + tsrc;
+              dtap = taps - 1 - tsrc;
+            } else {
+              idx = ((long)n * S.cin_src + (S.src_off + cc)) * taps + tsrc;
+            }
             val = S.src[idx] * sc;
             break;
           }
         }
       }
-      v[e] = val;
+      tile[dtap * PACK_PLANE + ((cl >> 3) * 32 + row) * 8 + (cl & 7)] = val;
     }
-    store_oct(dst + o * 8, v);
+    __syncthreads();
+    T* d = dst + (long)u * taps * 512;
+    for (int o = threadIdx.x; o < taps * 64; o += blockDim.x) {
+      const int t = o >> 6, r = o & 63;
+      store_oct(d + (long)o * 8, &tile[t * PACK_PLANE + r * 8]);
+    }
+    __syncthreads();
   }
   if (blockIdx.x == 0 && L.dst_bias) {
     for (int i = threadIdx.x; i < L.nblk * 32; i += blockDim.x) {
@@ -578,7 +602,7 @@ int srx_c8_to_nchw(int dtype, const void* src, int64_t src_is, float* dst, int B
 int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs,
                             const float* const* seg_scale_ptr, int nlayers, int64_t max_elems, void* stream) {
   SRX_CHECK_ARG(layers && segs && nlayers > 0 && max_elems > 0, "srx_pack_weights: bad argument");
-  dim3 grid(grid_for(max_elems / 8, TPB, 64), nlayers);
+  dim3 grid(grid_for(max_elems / 512, 1, 64), nlayers);   // (block, chunk) units, at least taps*512 values each
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(pack_kernel<bf16>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr),
              hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr));
