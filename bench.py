@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="replay recorded op lists as HIP graphs (0/1)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: run the gradient exchange over RCCL even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,9 +156,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        # the collectives' stream at high priority: its own pool of hardware queues, so it never
+        # shares one with the launch chain (normal) or the weight-gradient stream (low)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
 
     import ctypes
     G = importlib.import_module("super-resolution_amd.esrgan.generator")
@@ -170,7 +179,7 @@ def main():
         return bench_inference(args, dev, rank, world)
     adv = args.workload == "c3"
     B, h = args.batch, args.patch or (32 if adv else 64)
-    sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0) if world > 1 else None
+    sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0, single_rank_too=True) if exchange else None
     if args.skip_wgrad:
         E.Plan.wgrad = lambda self, ops, *a, **k: None
     E.Plan.use_graphs = bool(args.graphs)
@@ -187,7 +196,7 @@ def main():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")            # synthetic VGG weights: there is no network
             vgg = Lm.VGGLoss(device=dev)
-        sync_d = D.FlatGradAllReduce(world) if world > 1 else None
+        sync_d = D.FlatGradAllReduce(world, single_rank_too=True) if exchange else None
         trainer = T.AdversarialTrainer(gen, disc, vgg, (B, 3, h, h), torch.bfloat16, grad_sync_g=sync,
                                        grad_sync_d=sync_d)
     else:

@@ -371,6 +371,16 @@ int srx_graph_capture(const srx_op* ops, int n, void** graph_exec);
 int srx_graph_launch(void* graph_exec, void* stream);
 int srx_graph_destroy(void* graph_exec);
 
+/* A non-blocking stream of the given HIP priority (1 low, 0 normal, -1 high) on the current
+ * device, for the weight-gradient launches that run beside the data-gradient chain.  The runtime
+ * keeps one pool of hardware queues per priority (four queues each by default): a side stream of
+ * NORMAL priority created after a few others (a process group's, a data loader's) can land on
+ * the caller's own hardware queue, and the two launch chains then run one after the other
+ * instead of side by side; a stream of another priority never shares a queue with it.
+ * No counterpart in the reference (single stream, esrgan/train_esrgan.py:80-118). */
+int srx_stream_create(int priority, void** stream);
+int srx_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

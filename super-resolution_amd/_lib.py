@@ -142,6 +142,8 @@ _SIGS = {
     "srx_graph_capture": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "srx_graph_launch": (C.c_int, [vp, vp]),
     "srx_graph_destroy": (C.c_int, [vp]),
+    "srx_stream_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "srx_stream_destroy": (C.c_int, [vp]),
     "srx_tile_gather": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
     "srx_crop_augment": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "srx_tile_blend": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,

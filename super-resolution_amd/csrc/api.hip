@@ -145,4 +145,21 @@ int srx_graph_destroy(void* graph_exec) {
   return SRX_OK;
 }
 
+int srx_stream_create(int priority, void** stream) {
+  SRX_CHECK_ARG(stream != nullptr, "srx_stream_create: null result pointer");
+  int least = 0, greatest = 0;
+  SRX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  SRX_CHECK_ARG(priority <= least && priority >= greatest, "srx_stream_create: priority %d outside [%d, %d]",
+                priority, greatest, least);
+  hipStream_t s = nullptr;
+  SRX_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+  *stream = s;
+  return SRX_OK;
+}
+
+int srx_stream_destroy(void* stream) {
+  if (stream) SRX_CHECK_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+  return SRX_OK;
+}
+
 }  // extern "C"

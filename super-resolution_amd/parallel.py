@@ -32,16 +32,20 @@ class FlatGradAllReduce:
     xGMI's per-link-bound rings (a few tens of MB keeps every link busy without
     serialising the whole 68 MB generator gradient behind one launch)."""
 
-    def __init__(self, world_size: Optional[int] = None, bucket_mb: float = 24.0, group=None):
+    def __init__(self, world_size: Optional[int] = None, bucket_mb: float = 24.0, group=None,
+                 single_rank_too: bool = False):
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
+        # a one-rank group normally skips the collectives; single_rank_too issues them anyway
+        # (a rehearsal of the whole exchange on one GPU)
+        self.active = self.world > 1 or single_rank_too
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) // 4))
 
     def buckets(self, n: int) -> List[slice]:
         return [slice(i, min(n, i + self.bucket_elems)) for i in range(0, n, self.bucket_elems)]
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         use_avg = dist.get_backend(self.group) == "nccl"        # gloo has no AVG
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -72,7 +76,7 @@ class OverlappedGradAllReduce(FlatGradAllReduce):
         self._flat = flat_grad
         self._works = []
         self._pending: Optional[List[int]] = None
-        backend = dist.get_backend(self.group) if self.world > 1 else ""
+        backend = dist.get_backend(self.group) if self.active else ""
         self._avg = backend == "nccl"
 
     def _flush(self) -> None:
@@ -80,7 +84,7 @@ class OverlappedGradAllReduce(FlatGradAllReduce):
             return
         lo, hi = self._pending
         self._pending = None
-        if self.world > 1:
+        if self.active:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             if self._flat.is_cuda and not self._avg:
                 _host_staged_sum(self._flat[lo:hi], self.group)
@@ -103,7 +107,7 @@ class OverlappedGradAllReduce(FlatGradAllReduce):
         for w in self._works:
             w.wait()
         self._works = []
-        if self.world > 1 and not self._avg:
+        if self.active and not self._avg:
             self._flat.div_(self.world)
 
 
