@@ -11,14 +11,26 @@ from torch import nn
 
 
 def flatten_parameters(module: nn.Module) -> torch.Tensor:
-    """Re-point ``p.data`` of every parameter at a slice of one new flat tensor
-    (values preserved).  Returns the flat tensor.  Optimizers created earlier keep
-    working: they hold the Parameter objects, not their storage."""
+    """Re-point ``p.data`` of every parameter at a slice of one flat tensor (values
+    preserved) and return it; a second call on an intact module returns the same tensor.
+    Optimizers created earlier keep working: they hold the Parameter objects, not their
+    storage."""
     params: List[nn.Parameter] = list(module.parameters())
     if not params:
         raise ValueError("module has no parameters")
     dev, dt = params[0].device, params[0].dtype
     total = sum(p.numel() for p in params)
+    # Already flat (an earlier trainer of the same module did it) and still intact — .to() or
+    # .half() since then would have given the parameters new storage: hand out the same buffer,
+    # so that every trainer, optimizer and plan of the module keeps seeing one set of weights.
+    prev = module.__dict__.get("_srx_flat")
+    if prev is not None and prev.numel() == total and prev.device == dev and prev.dtype == dt:
+        off, ok = 0, True
+        for p in params:
+            ok = ok and p.data.data_ptr() == prev.data_ptr() + off * prev.element_size() and p.data.is_contiguous()
+            off += p.numel()
+        if ok:
+            return prev
     flat = torch.empty(total, dtype=dt, device=dev)
     off = 0
     with torch.no_grad():
@@ -27,6 +39,7 @@ def flatten_parameters(module: nn.Module) -> torch.Tensor:
             flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = flat[off:off + n].view(p.shape)
             off += n
+    module.__dict__["_srx_flat"] = flat
     return flat
 
 

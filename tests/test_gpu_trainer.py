@@ -152,3 +152,70 @@ def test_validator_psnr_matches_oracle():
     assert abs(res["val_sr_psnr"] - sum(sr) / 2) < 1e-3
     assert abs(res["val_bicubic_psnr"] - sum(bi) / 2) < 1e-3
     assert abs(res["improvement"] - 100 * (1 - (sum(sr) / 2) / (sum(bi) / 2))) < 1e-2
+
+
+def _toy_loader(n_batches, B, h, seed):
+    """(lr, hr) batches in [-1, 1]: smooth random HR images and their 4x box-downscaled LR."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        coarse = torch.rand((B, 3, h // 2, h // 2), generator=g) * 2 - 1
+        hr = torch.nn.functional.interpolate(coarse, size=(4 * h, 4 * h), mode="bilinear", align_corners=False)
+        lr = torch.nn.functional.avg_pool2d(hr, 4)
+        out.append((lr, hr))
+    return out
+
+
+def test_fit_pretrain_train_checkpoint_resume(tmp_path):
+    """The epoch harness (counterpart of esrgan/train_esrgan.py:121-208): pre-training writes
+    generator_pretrained.pth, every epoch leaves exactly one latest_checkpoint_epoch_{n}.pth with the
+    reference's keys, best_generator.pth follows the validation PSNR, the learning rate follows the
+    cosine schedule, and a resumed run continues the optimizer state where the first one stopped."""
+    TE = pkg("esrgan.train_esrgan")
+    T = pkg("train")
+    g, d, vgg = _models(num_blocks=1)
+    shape = (2, 3, 16, 16)
+    train, val = _toy_loader(3, 2, 16, 1), _toy_loader(2, 2, 16, 2)
+    logs = []
+    hist = TE.fit(g, d, vgg, train, val, tmp_path, batch_shape=shape, epochs=2, pretrain_epochs=1, mode="all",
+                  lr=1e-4, compute_dtype=torch.float32, log=logs.append)
+    assert [r["epoch"] for r in hist] == [1, 2]
+    assert (tmp_path / "generator_pretrained.pth").exists() and (tmp_path / "best_generator.pth").exists()
+    assert sorted(p.name for p in tmp_path.glob("latest_checkpoint_*.pth")) == ["latest_checkpoint_epoch_2.pth"]
+    for r in hist:
+        for k in ("loss_disc", "loss_gen", "gen_adv_loss", "gen_l1_loss", "gen_vgg_loss", "val_sr_psnr",
+                  "val_bicubic_psnr"):
+            assert math.isfinite(r[k]), (k, r[k])
+        assert abs(r["lr"] - T.cosine_lr(1e-4, r["epoch"] - 1, t_max=2)) < 1e-12
+    assert hist[-1]["best_psnr"] == max(r["val_sr_psnr"] for r in hist)
+    ck = torch.load(tmp_path / "latest_checkpoint_epoch_2.pth", weights_only=True)
+    assert set(ck) == {"epoch", "gen_state_dict", "disc_state_dict", "opt_g_state_dict", "opt_d_state_dict", "best_psnr"}
+    assert ck["epoch"] == 2 and list(ck["gen_state_dict"]) == list(g.state_dict())
+    # stock torch modules of the same architecture accept the files (what the reference's resume does)
+    opt = torch.optim.Adam(g.parameters(), lr=1e-4)
+    opt.load_state_dict(ck["opt_g_state_dict"])
+    assert int(opt.state_dict()["state"][0]["step"]) == 6          # 3 batches x 2 epochs
+
+    # resume into fresh modules: one more epoch, optimizer steps continue from 6
+    g2, d2, vgg2 = _models(num_blocks=1)
+    hist2 = TE.fit(g2, d2, vgg2, train, val, tmp_path, batch_shape=shape, epochs=3, pretrain_epochs=1, mode="all",
+                   resume=True, lr=1e-4, compute_dtype=torch.float32, log=logs.append)
+    assert [r["epoch"] for r in hist2] == [3]
+    assert sorted(p.name for p in tmp_path.glob("latest_checkpoint_*.pth")) == ["latest_checkpoint_epoch_3.pth"]
+    ck3 = torch.load(tmp_path / "latest_checkpoint_epoch_3.pth", weights_only=True)
+    assert int(ck3["opt_g_state_dict"]["state"][0]["step"]) == 9
+    assert ck3["best_psnr"] >= ck["best_psnr"]
+    assert any("Resumed from epoch 2" in m for m in logs)
+
+
+def test_flatten_parameters_is_idempotent():
+    F = pkg("utils.flat")
+    G = pkg("esrgan.generator")
+    g = G.GeneratorESRGAN(num_blocks=1).cuda()
+    a = F.flatten_parameters(g)
+    b = F.flatten_parameters(g)
+    assert a.data_ptr() == b.data_ptr()
+    g.half().float()                     # new parameter storage: the old flat buffer no longer backs the module
+    c = F.flatten_parameters(g)
+    assert c.data_ptr() != a.data_ptr()
+    assert next(g.parameters()).data_ptr() == c.data_ptr()
