@@ -143,3 +143,31 @@ def test_conv_pair_matches_two_convs(shape, mode):
     assert float(a0.abs().max()) > 0 and float(b0.abs().max()) > 0
     assert torch.equal(a0, a1)                                     # same arithmetic, same order
     assert rel_err(b1, b0) < 1e-2                                  # bf16; accumulation order may differ
+
+
+def test_stream_create_priorities_and_side_stream():
+    """srx_stream_create: low / normal / high priority streams run the same convolution to the same
+    bits; a priority outside the device's range is an argument error; engine.side_stream hands out
+    one low-priority stream per device."""
+    import ctypes as C
+    E, L = pkg("engine"), pkg("_lib")
+    lib = L.lib()
+    x = O.hash_input("xs", (2, 64, 16, 32))
+    w = O.hash_uniform("ws", (32, 64, 3, 3), 0.05)
+    b = O.hash_uniform("bs", (32,), 0.1)
+    base = run_single_conv(x, w, b, tdtype=torch.bfloat16, act=0.2)
+    for prio in (1, 0, -1):
+        sp = C.c_void_p()
+        assert lib.srx_stream_create(prio, C.byref(sp)) == 0 and sp.value
+        st = torch.cuda.ExternalStream(sp.value)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            out = run_single_conv(x, w, b, tdtype=torch.bfloat16, act=0.2)
+        st.synchronize()
+        assert torch.equal(out, base)
+        assert lib.srx_stream_destroy(sp) == 0
+    sp = C.c_void_p()
+    assert lib.srx_stream_create(7, C.byref(sp)) != 0
+    assert b"priority" in lib.srx_last_error()
+    s1, s2 = E.side_stream(torch.device("cuda")), E.side_stream(torch.device("cuda", 0))
+    assert s1 is s2
