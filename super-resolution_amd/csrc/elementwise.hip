@@ -72,56 +72,67 @@ __global__ void c8_to_nchw_kernel(const T* __restrict__ src, long src_is, float*
 // transposed segments), dropped into an LDS image of the packed layout, and written out as whole
 // 16/32-byte octets — both sides of the gather are coalesced.
 constexpr int PACK_PLANE = 520;   // floats per tap plane in LDS (512 + a bank offset of 8)
-template <typename T>
-__global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
-                            const srx_pack_seg* __restrict__ segs,
-                            const float* const* __restrict__ seg_scale_ptr) {
-  __shared__ __attribute__((aligned(16))) float tile[9 * PACK_PLANE];
-  const srx_pack_layer L = layers[blockIdx.y];
-  const int taps = L.taps;
+struct PackCol { const float* base; int nstep; float scale; int flip; };
+constexpr int PACK_MAX_SEGS = 8;     // segments of a layer cached in LDS (a dense block's backward has 5)
+template <typename T, int taps>      // taps is a compile-time constant: the index arithmetic is all divisions by it
+__device__ __forceinline__ void pack_units(const srx_pack_layer& L, const srx_pack_seg* __restrict__ segs,
+                                           const float* const* __restrict__ seg_scale_ptr, float* tile,
+                                           srx_pack_seg* ssegs, PackCol* cols) {
   const int nunits = L.nblk * L.nchunk;
-  const int per = 512 * taps;
+  static_assert(512 % TPB == 0, "pairs per thread");
   T* dst = reinterpret_cast<T*>(L.dst_w);
-  const bool tr = L.seg_count > 0 && segs[L.seg_begin].transposed != 0;   // read order only
+  // the layer's segments, with the run-time scale folded in, next to the tile
+  const int nseg = L.seg_count < PACK_MAX_SEGS ? L.seg_count : PACK_MAX_SEGS;
+  if ((int)threadIdx.x < nseg) {
+    srx_pack_seg S = segs[L.seg_begin + threadIdx.x];
+    if (seg_scale_ptr && seg_scale_ptr[L.seg_begin + threadIdx.x]) S.scale *= *seg_scale_ptr[L.seg_begin + threadIdx.x];
+    ssegs[threadIdx.x] = S;
+  }
+  __syncthreads();
+  const bool tr = nseg > 0 && ssegs[0].transposed != 0;   // read order only
   for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
     const int nb = u / L.nchunk, chunk = u - nb * L.nchunk;
-    for (int i = threadIdx.x; i < per; i += blockDim.x) {
-      int row, cl, tsrc;
-      if (!tr) {
-        row = i / (16 * taps);
-        const int rem = i - row * 16 * taps;
-        cl = rem / taps;
-        tsrc = rem - cl * taps;
-      } else {
-        cl = i / (32 * taps);
-        const int rem = i - cl * 32 * taps;
-        row = rem / taps;
-        tsrc = rem - row * taps;
-      }
-      const int n = nb * 32 + srx_row_to_chan(row, L.perm);
-      const int c = chunk * 16 + cl;
-      float val = 0.f;
-      int dtap = tsrc;
-      if (n < L.cout && c < L.cin) {
-        for (int sI = L.seg_begin; sI < L.seg_begin + L.seg_count; ++sI) {
-          const srx_pack_seg S = segs[sI];
+    // per input channel of the chunk (16 of them): where its source run starts for output channel 0,
+    // the step per output channel, the scale, and whether the taps are flipped — one segment
+    // look-up per channel instead of one per (row, channel)
+    if (threadIdx.x < 16) {
+      const int c = chunk * 16 + (int)threadIdx.x;
+      PackCol col = {nullptr, 0, 0.f, 0};
+      if (c < L.cin) {
+        for (int sI = 0; sI < L.seg_count; ++sI) {
+          const srx_pack_seg& S = sI < PACK_MAX_SEGS ? ssegs[sI] : segs[L.seg_begin + sI];
           if (c >= S.c_begin && c < S.c_begin + S.c_count) {
-            float sc = S.scale;
-            if (seg_scale_ptr && seg_scale_ptr[sI]) sc *= *seg_scale_ptr[sI];
+            col.scale = S.scale;
+            if (sI >= PACK_MAX_SEGS && seg_scale_ptr && seg_scale_ptr[L.seg_begin + sI])
+              col.scale *= *seg_scale_ptr[L.seg_begin + sI];
             const int cc = c - S.c_begin;
-            long idx;
-            if (S.transposed) {
-              idx = ((long)(S.src_o_off + cc) * S.cin_src + (S.src_off + n)) * taps + tsrc;
-              dtap = taps - 1 - tsrc;
-            } else {
-              idx = ((long)n * S.cin_src + (S.src_off + cc)) * taps + tsrc;
-            }
-            val = S.src[idx] * sc;
+            col.flip = S.transposed != 0;
+            col.base = S.src + (col.flip ? ((long)(S.src_o_off + cc) * S.cin_src + S.src_off) * taps
+                                         : (long)(S.src_off + cc) * taps);
+            col.nstep = col.flip ? taps : S.cin_src * taps;
             break;
           }
         }
       }
-      tile[dtap * PACK_PLANE + ((cl >> 3) * 32 + row) * 8 + (cl & 7)] = val;
+      cols[threadIdx.x] = col;
+    }
+    __syncthreads();
+    // a thread owns (row, channel) pairs: `taps` consecutive source floats each; neighbouring lanes
+    // hold neighbouring runs of the source
+#pragma unroll
+    for (int k = 0; k < 512 / TPB; ++k) {
+      const int pr = k * TPB + (int)threadIdx.x;
+      const int row = tr ? (pr & 31) : (pr >> 4);
+      const int cl = tr ? (pr >> 5) : (pr & 15);
+      const int n = nb * 32 + srx_row_to_chan(row, L.perm);
+      const PackCol col = cols[cl];
+      const float* src = (n < L.cout && col.base) ? col.base + (long)n * col.nstep : nullptr;
+      float v[taps];
+#pragma unroll
+      for (int t = 0; t < taps; ++t) v[t] = src ? src[t] * col.scale : 0.f;
+      float* out = tile + ((cl >> 3) * 32 + row) * 8 + (cl & 7);
+#pragma unroll
+      for (int t = 0; t < taps; ++t) out[(col.flip ? taps - 1 - t : t) * PACK_PLANE] = v[t];
     }
     __syncthreads();
     T* d = dst + (long)u * taps * 512;
@@ -131,12 +142,32 @@ __global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0 && L.dst_bias) {
-    for (int i = threadIdx.x; i < L.nblk * 32; i += blockDim.x) {
-      int nb = i >> 5, hh = (i >> 4) & 1, reg = i & 15;
-      int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-      int n = nb * 32 + srx_row_to_chan(row, L.perm);
-      L.dst_bias[i] = (L.src_bias && n < L.cout) ? L.src_bias[n] : 0.f;
+}
+
+// grid = (units, ceil(nlayers / PACK_LPB)): a workgroup serves its unit index in PACK_LPB consecutive
+// layers.  Most layers have far fewer units than the largest one, and a launch of (max units x
+// layers) workgroups that exit at once is bound by the dispatcher (45 000 workgroups: 150 us).
+constexpr int PACK_LPB = 2;
+template <typename T>
+__global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
+                            const srx_pack_seg* __restrict__ segs,
+                            const float* const* __restrict__ seg_scale_ptr, int nlayers) {
+  __shared__ __attribute__((aligned(16))) float tile[9 * PACK_PLANE];
+  __shared__ srx_pack_seg ssegs[PACK_MAX_SEGS];
+  __shared__ PackCol cols[16];
+  for (int li = blockIdx.y * PACK_LPB; li < nlayers && li < (int)(blockIdx.y + 1) * PACK_LPB; ++li) {
+    const srx_pack_layer L = layers[li];
+    if ((int)blockIdx.x < L.nblk * L.nchunk) {
+      if (L.taps == 9) pack_units<T, 9>(L, segs, seg_scale_ptr, tile, ssegs, cols);
+      else if (L.taps == 1) pack_units<T, 1>(L, segs, seg_scale_ptr, tile, ssegs, cols);
+    }
+    if (blockIdx.x == 0 && L.dst_bias) {
+      for (int i = threadIdx.x; i < L.nblk * 32; i += blockDim.x) {
+        int nb = i >> 5, hh = (i >> 4) & 1, reg = i & 15;
+        int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        int n = nb * 32 + srx_row_to_chan(row, L.perm);
+        L.dst_bias[i] = (L.src_bias && n < L.cout) ? L.src_bias[n] : 0.f;
+      }
     }
   }
 }
@@ -602,10 +633,10 @@ int srx_c8_to_nchw(int dtype, const void* src, int64_t src_is, float* dst, int B
 int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs,
                             const float* const* seg_scale_ptr, int nlayers, int64_t max_elems, void* stream) {
   SRX_CHECK_ARG(layers && segs && nlayers > 0 && max_elems > 0, "srx_pack_weights: bad argument");
-  dim3 grid(grid_for(max_elems / 512, 1, 64), nlayers);   // (block, chunk) units, at least taps*512 values each
+  dim3 grid(grid_for(max_elems / 512, 1, 64), (nlayers + PACK_LPB - 1) / PACK_LPB);   // x: (block, chunk) units, at least taps*512 values each
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(pack_kernel<bf16>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr),
-             hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr));
+             hipLaunchKernelGGL(pack_kernel<bf16>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, nlayers),
+             hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, nlayers));
   return srx_check_launch("pack_kernel");
 }
 
