@@ -461,29 +461,33 @@ class Plan:
     def split_ops(main: "OpList", side_marks: List[Tuple[int, "OpList", List[str]]]):
         """main: ops of the chain; side_marks: (number of chain ops that must precede, ops,
         names of the parameters whose gradients those ops complete).
-        Returns (segments, serial ops, serial meta, names per segment): segments =
-        [(chain ops, side ops|None)]; the serial list interleaves both in dependency order
-        for one-stream profiling."""
-        segs, serial, meta = [], [], []
+        Returns (segments, serial ops, serial meta, names per segment, meta per segment):
+        segments = [(chain ops, side ops|None)]; the serial list interleaves both in dependency
+        order for one-stream runs; meta per segment = (chain meta, side meta) for profiling the
+        two-stream form."""
+        segs, serial, meta, seg_meta = [], [], [], []
         pos = 0
         for after, ops, names in side_marks:
             if after > pos or not segs:
                 chunk = main[pos:after]
                 segs.append([list(chunk), list(ops), list(names)])
+                seg_meta.append([list(main.meta[pos:after]), list(ops.meta)])
                 serial += chunk
                 meta += main.meta[pos:after]
                 pos = after
             else:
                 segs[-1][1] += list(ops)
                 segs[-1][2] += list(names)
+                seg_meta[-1][1] += list(ops.meta)
             serial += ops
             meta += ops.meta
         if pos < len(main) or not segs:
             segs.append([list(main[pos:]), [], []])
+            seg_meta.append([list(main.meta[pos:]), []])
             serial += main[pos:]
             meta += main.meta[pos:]
         frozen = [(Plan.freeze(a), Plan.freeze(b)) for a, b, _ in segs]
-        return frozen, Plan.freeze(serial), meta, [n for _, _, n in segs]
+        return frozen, Plan.freeze(serial), meta, [n for _, _, n in segs], seg_meta
 
     def run_split(self, segments, side_hook=None) -> None:
         """side_hook(i), if given, is called with the side stream current right after segment
@@ -677,6 +681,7 @@ class _GenBase(Plan):
 
     # ---- shared run API ---------------------------------------------------
     bwd_segments = None     # two-stream form of bwd_ops (Plan.split_ops), when the plan built one
+    bwd_seg_meta = None     # (kernel name, flops) of every op of those segments
 
     bwd_seg_ranges = None   # per segment: [(first item, item count, flat offset, flat end)] completed by it
 
@@ -906,7 +911,8 @@ class GeneratorPlan(_GenBase):
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
         if self.overlap_wgrad:
-            self.bwd_segments, self.bwd_ops, self.bwd_meta, seg_names = self.split_ops(bwd, side_marks)
+            self.bwd_segments, self.bwd_ops, self.bwd_meta, seg_names, self.bwd_seg_meta = \
+                self.split_ops(bwd, side_marks)
             self.bwd_seg_ranges = self._ranges_for(seg_names)
         else:
             self.bwd_ops = self.freeze(bwd)
