@@ -204,14 +204,18 @@ class Plan:
         self._pack_dev = (self.upload(la), self.upload(sa), self.upload(pa))
         self._pack_scaled = any(self.pack_scale_ptrs)
 
-    def run_packing(self):
+    def run_packing(self, first: int = 0, count: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+        """Pack layers [first, first+count) of the table (default: all) on `stream` (default: current)."""
         if self._pack_dev is None:
             return
+        count = len(self.pack_layers) - first if count is None else count
+        if count <= 0:
+            return
         la, sa, pa = self._pack_dev
-        rc = self.lib.srx_pack_weights_scaled(self.dt, la.data_ptr(), sa.data_ptr(),
+        sp = stream.cuda_stream if stream is not None else stream_ptr(self.device)
+        rc = self.lib.srx_pack_weights_scaled(self.dt, la.data_ptr() + first * C.sizeof(L.PackLayer), sa.data_ptr(),
                                               pa.data_ptr() if self._pack_scaled else None,
-                                              len(self.pack_layers), self.pack_max_elems,
-                                              stream_ptr(self.device))
+                                              count, self.pack_max_elems, sp)
         L.check(rc, "srx_pack_weights")
 
     # --------------------------------------------------------------- ops
@@ -683,6 +687,9 @@ class _GenBase(Plan):
     bwd_segments = None     # two-stream form of bwd_ops (Plan.split_ops), when the plan built one
     bwd_seg_meta = None     # (kernel name, flops) of every op of those segments
 
+    _pack_evs = None        # (parameters final, backward weights packed) when backward's packing runs aside
+    _bwd_pack_pending = False
+    _n_fwd_layers = 0
     bwd_seg_ranges = None   # per segment: [(first item, item count, flat offset, flat end)] completed by it
 
     def run_backward_ops(self, on_grads_ready=None) -> bool:
@@ -690,6 +697,9 @@ class _GenBase(Plan):
         two-stream form, is called (side stream current) as soon as flat_grad[lo:hi] is final
         and unpacked — the hook a data-parallel exchange overlaps with the rest of backward.
         Returns True if the gradients were delivered that way (run_unpack is then not needed)."""
+        if self._bwd_pack_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._pack_evs[1])
+            self._bwd_pack_pending = False
         if self.bwd_segments is None:
             self.run(self.bwd_ops)
             return False
@@ -792,6 +802,7 @@ class GeneratorPlan(_GenBase):
         self.fwd_meta = fwd.meta
         self.bwd_ops = None
         self.param_names = [n for n in P]
+        self._n_fwd_layers = len(self.pack_layers)      # the layers after these belong to backward
         if need_grad:
             self._build_backward(P, Rb, flat_grad)
         self.finalize_packing()
@@ -921,7 +932,22 @@ class GeneratorPlan(_GenBase):
     # ------------------------------------------------------------------ API
     def forward_c8(self, x_nchw: torch.Tensor) -> Buf:
         """Pack weights, convert the input and run the forward ops; returns Y (C8)."""
-        self.run_packing()
+        nf_ = self._n_fwd_layers
+        if self.bwd_segments is not None and len(self.pack_layers) > nf_:
+            # the data-gradient weights (transposed, tap-flipped stacks) are first needed when
+            # backward starts: packed on the side stream, under the forward pass
+            main, side = torch.cuda.current_stream(self.device), side_stream(self.device)
+            if self._pack_evs is None:
+                self._pack_evs = (torch.cuda.Event(), torch.cuda.Event())
+            ready, done = self._pack_evs
+            ready.record(main)                       # parameters are final here (optimizer step is behind us)
+            self.run_packing(0, nf_)
+            side.wait_event(ready)
+            self.run_packing(nf_, None, stream=side)
+            done.record(side)
+            self._bwd_pack_pending = True
+        else:
+            self.run_packing()
         self.nchw_to_c8(x_nchw, (self.X0, 0))
         self.run(self.fwd_ops)
         return self.Y

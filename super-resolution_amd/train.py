@@ -248,6 +248,11 @@ class AdversarialTrainer:
         self.grad_sync_g, self.grad_sync_d = grad_sync_g, grad_sync_d
         self.steps = 0
         self.B = B
+        self._ev_in, self._ev_real, self._ev_y, self._ev_vgg = (torch.cuda.Event() for _ in range(4))
+
+    # D(hr) pass and VGG(hr) features beside the generator forward, the perceptual branch beside
+    # the discriminator step and the adversarial branch
+    overlap_real_pass = True
 
     def set_lr(self, lr: float) -> None:
         self.opt_g.lr = lr
@@ -265,14 +270,51 @@ class AdversarialTrainer:
                                    plan.gA[-1].ptr(), 1.0, sp), "srx_bce_logits")
         plan.backward_c8()
 
+    def _vgg_branch(self, Y, fb, l_percep: float) -> None:
+        """VGGLoss(fake, hr) (utils/loss.py:21) and its gradient w.r.t. fake, on the current stream."""
+        vf = self.v_fake
+        vf.A[0].t.copy_(Y.t)
+        fa = vf.forward_c8(None, pack=False)
+        Bf, Cf, Hf, Wf = vf.geo[-1]
+        g = vf.gA[-1]
+        L.check(vf.lib.srx_l1_c8(vf.dt, fa.ptr(), fa.img_stride, fb.ptr(), fb.img_stride, self._acc_ptr(3),
+                                 g.ptr(), g.img_stride, l_percep, 0.0, Bf, Cf, Hf, Wf,
+                                 engine.stream_ptr(self.device)), "srx_l1_c8")
+        vf.backward_c8()
+
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
         lr_img, hr_img = lr_img.contiguous(), hr_img.contiguous()
         gp, lib = self.gplan, self.gplan.lib
         sp = engine.stream_ptr(self.device)
         l_l1, l_adv, l_percep = self.lams
-        Y = gp.forward_c8(lr_img)
-        # ---- discriminator step (esrgan/train_esrgan.py:89-98)
-        self._d_pass(self.d_real, hr_img, None, 1.0)
+        vf, vr = self.v_fake, self.v_real
+        if self.overlap_real_pass:
+            # Everything that needs only the HR batch — D(hr) forward + backward and the VGG
+            # features of hr — runs on the side stream under the generator's forward pass (a chain
+            # of short launches that leaves most of the chip idle).  The order of the three
+            # spectral-norm updates (real, fake, generator step) is kept by the event below.
+            main, side = torch.cuda.current_stream(self.device), engine.side_stream(self.device)
+            self._ev_in.record(main)
+            side.wait_event(self._ev_in)
+            with torch.cuda.stream(side):
+                self._d_pass(self.d_real, hr_img, None, 1.0)
+                fb = vr.forward_c8(hr_img, pack=False)
+                self._ev_real.record(side)
+            Y = gp.forward_c8(lr_img)
+            main.wait_event(self._ev_real)
+        else:
+            Y = gp.forward_c8(lr_img)
+            # ---- discriminator step (esrgan/train_esrgan.py:89-98)
+            self._d_pass(self.d_real, hr_img, None, 1.0)
+            fb = vr.forward_c8(hr_img, pack=False)
+        if self.overlap_real_pass:
+            # the perceptual branch (VGG(fake) forward, L1 against VGG(hr), data gradient back to
+            # fake) needs only Y: beside the discriminator step and the adversarial branch
+            self._ev_y.record(main)
+            side.wait_event(self._ev_y)
+            with torch.cuda.stream(side):
+                self._vgg_branch(Y, fb, l_percep)
+                self._ev_vgg.record(side)
         self._d_pass(self.d_fake, None, Y, 0.0)
         gd = self.d_real.flat_grad
         L.check(lib.srx_axpby(L.F32, self.d_fake.flat_grad.data_ptr(), gd.data_ptr(), 1.0, 1.0, gd.numel(), sp),
@@ -287,15 +329,10 @@ class AdversarialTrainer:
         L.check(lib.srx_bce_logits(dg.dt, out.ptr(), self.B, 1.0, 1.0, self._acc_ptr(1), dg.gA[-1].ptr(),
                                    l_adv, sp), "srx_bce_logits")
         dg.backward_c8()
-        vf, vr = self.v_fake, self.v_real
-        vf.A[0].t.copy_(Y.t)
-        fa = vf.forward_c8(None, pack=False)
-        fb = vr.forward_c8(hr_img, pack=False)
-        Bf, Cf, Hf, Wf = vf.geo[-1]
-        g = vf.gA[-1]
-        L.check(lib.srx_l1_c8(vf.dt, fa.ptr(), fa.img_stride, fb.ptr(), fb.img_stride, self._acc_ptr(3),
-                              g.ptr(), g.img_stride, l_percep, 0.0, Bf, Cf, Hf, Wf, sp), "srx_l1_c8")
-        vf.backward_c8()
+        if self.overlap_real_pass:
+            main.wait_event(self._ev_vgg)
+        else:
+            self._vgg_branch(Y, fb, l_percep)
         L.check(lib.srx_l1_c8_nchw(gp.dt, Y.ptr(), Y.img_stride, hr_img.data_ptr(), self._acc_ptr(2),
                                    gp.GY.ptr(), gp.GY.img_stride, l_l1, Y.B, gp.out_ch, Y.H, Y.W, sp),
                 "srx_l1_c8_nchw")
