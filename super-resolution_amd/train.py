@@ -295,12 +295,14 @@ class AdversarialTrainer:
             # spectral-norm updates (real, fake, generator step) is kept by the event below.
             main, side = torch.cuda.current_stream(self.device), engine.side_stream(self.device)
             self._ev_in.record(main)
+            # the generator's launches are enqueued first: the host needs ~3.5 us per launch, and
+            # the longer chain must not wait for the shorter one to be enqueued
+            Y = gp.forward_c8(lr_img)
             side.wait_event(self._ev_in)
             with torch.cuda.stream(side):
                 self._d_pass(self.d_real, hr_img, None, 1.0)
                 fb = vr.forward_c8(hr_img, pack=False)
                 self._ev_real.record(side)
-            Y = gp.forward_c8(lr_img)
             main.wait_event(self._ev_real)
         else:
             Y = gp.forward_c8(lr_img)
