@@ -57,6 +57,10 @@ class Discriminator(_SrxHost):
         return chain.DiscriminatorPlan(params, buffers, B, h, w, tdtype,
                                        need_param_grad=need_grad, need_input_grad=need_input_grad)
 
+    def _out_shape(self, shape):
+        self._check_channels(shape, self.features[0][0].in_channels)
+        return (shape[0], 1, 1, 1)
+
     def forward(self, x):
         x = self._run(x)
         return x.view(x.size(0), -1)

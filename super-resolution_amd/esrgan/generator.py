@@ -38,6 +38,10 @@ class ResidualDenseBlock(_SrxHost):
         return engine.BlockPlan("rdb", params, B, h, w, tdtype, nf=nf, gc=gc,
                                 need_grad=need_grad, need_input_grad=need_input_grad)
 
+    def _out_shape(self, shape):
+        self._check_channels(shape, self.conv1.in_channels)
+        return shape
+
     def forward(self, x):
         return self._run(x)
 
@@ -56,6 +60,10 @@ class RRDB(_SrxHost):
         return engine.BlockPlan("rrdb", params, B, h, w, tdtype, nf=nf, gc=gc,
                                 need_grad=need_grad, need_input_grad=need_input_grad)
 
+    def _out_shape(self, shape):
+        self._check_channels(shape, self.rdb1.conv1.in_channels)
+        return shape
+
     def forward(self, x):
         return self._run(x)
 
@@ -73,6 +81,10 @@ class UpsampleBlock(_SrxHost):
     def _build_plan(self, params, B, h, w, tdtype, need_grad, need_input_grad):
         return engine.BlockPlan("upsample", params, B, h, w, tdtype, nf=self.conv.in_channels, gc=32,
                                 need_grad=need_grad, need_input_grad=need_input_grad)
+
+    def _out_shape(self, shape):
+        self._check_channels(shape, self.conv.in_channels)
+        return (shape[0], shape[1], 2 * shape[2], 2 * shape[3])
 
     def forward(self, x):
         return self._run(x)
@@ -100,6 +112,10 @@ class GeneratorESRGAN(_SrxHost):
                                     in_ch=self.conv_first.in_channels, out_ch=self.conv_last.out_channels,
                                     nf=self.conv_first.out_channels, gc=gc, num_blocks=len(self.body),
                                     need_grad=need_grad, need_input_grad=need_input_grad)
+
+    def _out_shape(self, shape):
+        self._check_channels(shape, self.conv_first.in_channels)
+        return (shape[0], self.conv_last.out_channels, 4 * shape[2], 4 * shape[3])
 
     def forward(self, x):
         return self._run(x)

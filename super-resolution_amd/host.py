@@ -139,9 +139,30 @@ class _SrxHost(nn.Module):
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g.to(p.grad.dtype))
 
+    def _out_shape(self, shape):          # pragma: no cover - overridden
+        """Output shape for an NCHW input shape; raises on a channel count the module was not built for."""
+        raise NotImplementedError
+
+    @staticmethod
+    def _check_channels(shape, expected: int) -> None:
+        if len(shape) != 4:
+            raise ValueError("expected a 4-D NCHW input")
+        if shape[1] != expected:
+            raise RuntimeError(f"expected input with {expected} channels, got {shape[1]} (shape {tuple(shape)})")
+
     def _run(self, x: torch.Tensor) -> torch.Tensor:
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        out_shape = self._out_shape(tuple(x.shape))
+        if x.shape[0] == 0:
+            # an empty batch launches nothing; like the stock layers it yields an empty result through
+            # which zero gradients reach the input and every parameter
+            if x.device.type != "cuda":
+                raise RuntimeError("libsrx modules run on a ROCm GPU only (input is on %s)" % x.device)
+            out = torch.zeros(out_shape, dtype=x.dtype, device=x.device)
+            if need_grad:
+                out = out + 0 * (x.sum() + sum(p.sum() for p in self.parameters() if p.requires_grad)).to(x.dtype)
+            return out
         if need_grad:
             anchor = torch.empty(0, device=x.device, requires_grad=True)
             return _PlanFn.apply(x, anchor, self)
