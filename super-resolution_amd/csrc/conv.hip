@@ -500,6 +500,12 @@ extern "C" int srx_conv2d(const srx_conv_desc* d, void* stream) {
                 "srx_conv2d: pixel_shuffle needs cout %% 32 == 0 and no mask/residual/alpha");
   SRX_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w) % 16 == 0,
                 "srx_conv2d: x/y/w must be 16-byte aligned");
+  // one image's input planes are addressed through a 32-bit buffer descriptor (offsets at and above
+  // 0xFFFFFFF0 are the "deposit zeros" marker): larger inputs must be tiled by the caller
+  const long x_bytes = (long)((d->cin + 7) / 8) * d->H * d->W * 8 * (d->dtype == SRX_BF16 ? 2 : 4);
+  SRX_CHECK_ARG(x_bytes < 0xFFFFFFF0L,
+                "srx_conv2d: one image's input (%ld bytes) exceeds the 4 GB a buffer descriptor addresses; "
+                "tile the image", x_bytes);
   ConvParams p;
   p.x = d->x; p.x_is = d->x_img_stride;
   p.y = d->y; p.y_is = d->y_img_stride;

@@ -431,6 +431,10 @@ extern "C" int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream) {
   SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->ntasks > 0 && d->nslices > 0,
                 "srx_conv2d_wgrad: non-positive size");
   SRX_CHECK_ARG(d->tasks, "srx_conv2d_wgrad: null task table");
+  // a task's 64 channels of one image are addressed through a 32-bit buffer descriptor with signed
+  // byte counts
+  SRX_CHECK_ARG((long)d->H * d->W * 64 * (d->dtype == SRX_BF16 ? 2 : 4) < (1L << 31),
+                "srx_conv2d_wgrad: image of %d x %d is too large for one launch; tile the image", d->H, d->W);
   WgradParams p;
   p.x = d->x; p.x_is = d->x_img_stride;
   p.gy = d->gy; p.gy_is = d->gy_img_stride;

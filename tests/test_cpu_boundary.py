@@ -49,6 +49,17 @@ def test_argument_errors_are_reported_not_thrown():
     assert b"dtype" in lib.srx_last_error()
     with pytest.raises(RuntimeError):
         L.check(1, "probe")
+    # one image's input beyond what a 32-bit buffer descriptor addresses: refused, never mis-addressed
+    d = L.ConvDesc(dtype=0, ksize=3, stride=1, B=1, H=8192, W=8192, cin=64, cout=64)
+    d.x = d.y = d.w = 16
+    assert lib.srx_conv2d(ctypes.byref(d), None) == 1
+    assert b"tile the image" in lib.srx_last_error()
+    w = L.WgradDesc(dtype=1, ksize=3, stride=1, B=1, H=4096, W=4096, ntasks=1, nslices=1)
+    w.tasks = 16
+    assert lib.srx_conv2d_wgrad(ctypes.byref(w), None) == 1
+    assert b"too large" in lib.srx_last_error()
+    assert lib.srx_stream_create(0, None) == 1
+    assert b"null" in lib.srx_last_error()
 
 
 def test_generator_state_dict_and_checkpoint_compat():
