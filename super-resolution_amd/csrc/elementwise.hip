@@ -212,34 +212,36 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, long is, int B, long
 template <typename T>
 __global__ void pixel_unshuffle2_kernel(const T* __restrict__ x, long x_is, T* __restrict__ y,
                                         long y_is, int B, int C, int H, int W) {
-  // x: C channels at 2H x 2W ; y: 4C channels at H x W ; y[4c+2i+j][h][w] = x[c][2h+i][2w+j]
+  // x: C channels at 2H x 2W ; y: 4C channels at H x W ; y[4c+2i+j][h][w] = x[c][2h+i][2w+j].
+  // A thread takes the 2x2 quad of one input octet (read once, 4 x 16 bytes) and writes the four
+  // output octets it becomes (input channels 2k, 2k+1 -> output octet 4*ci8 + k).
+  const int Ci8 = (C + 7) / 8;
   const int Co8 = (4 * C + 7) / 8;
   const long HW = (long)H * W;
-  const long n = (long)B * Co8 * HW;
+  const long n = (long)B * Ci8 * HW;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
-    long pix = idx % HW;
-    int oo = (int)((idx / HW) % Co8);
-    int b = (int)(idx / (HW * Co8));
-    int h = (int)(pix / W), w = (int)(pix % W);
-    const int c0 = 2 * oo;                 // output octet oo <- input channels c0, c0+1
-    const T* xp = x + (long)b * x_is + (long)(c0 >> 3) * (4 * HW * 8);
-    float v[8];
+    const long pix = idx % HW;
+    const int ci8 = (int)((idx / HW) % Ci8);
+    const int b = (int)(idx / (HW * Ci8));
+    const int h = (int)(pix / W), w = (int)(pix % W);
+    const T* xp = x + (long)b * x_is + (long)ci8 * (4 * HW * 8);
+    float t[4][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      int i = s >> 1, j = s & 1;
-      float t[8];
-      load_oct(xp + ((long)(2 * h + i) * (2 * W) + 2 * w + j) * 8, t);
-      v[s] = t[c0 & 7];
-      v[4 + s] = t[(c0 & 7) + 1];
+    for (int s = 0; s < 4; ++s)
+      load_oct(xp + ((long)(2 * h + (s >> 1)) * (2 * W) + 2 * w + (s & 1)) * 8, t[s]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oo = 4 * ci8 + k;
+      if (oo >= Co8) break;
+      const int c0 = ci8 * 8 + 2 * k;
+      float v[8];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        v[s] = c0 < C ? t[s][2 * k] : 0.f;
+        v[4 + s] = c0 + 1 < C ? t[s][2 * k + 1] : 0.f;
+      }
+      store_oct(y + (long)b * y_is + ((long)oo * HW + pix) * 8, v);
     }
-    if (c0 >= C) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    } else if (c0 + 1 >= C) {
-#pragma unroll
-      for (int e = 4; e < 8; ++e) v[e] = 0.f;
-    }
-    store_oct(y + (long)b * y_is + ((long)oo * HW + pix) * 8, v);
   }
 }
 
@@ -666,7 +668,7 @@ int srx_channel_sum(int dtype, const void* x, int64_t is, int noct, int B, int H
 int srx_pixel_unshuffle2(int dtype, const void* x, int64_t x_is, void* y, int64_t y_is, int B, int C,
                          int H, int W, void* stream) {
   SRX_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && C % 2 == 0, "srx_pixel_unshuffle2: bad argument");
-  long n = (long)B * ((4 * C + 7) / 8) * H * W;
+  long n = (long)B * ((C + 7) / 8) * H * W;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(pixel_unshuffle2_kernel<bf16>, dim3(grid_for(n)), dim3(TPB), 0, STREAM, (const bf16*)x, x_is, (bf16*)y, y_is, B, C, H, W),
              hipLaunchKernelGGL(pixel_unshuffle2_kernel<float>, dim3(grid_for(n)), dim3(TPB), 0, STREAM, (const float*)x, x_is, (float*)y, y_is, B, C, H, W));
