@@ -107,16 +107,16 @@ int srx_graph_capture(const srx_op* ops, int n, void** graph_exec) {
   SRX_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
   hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
-    hipStreamDestroy(cs);
+    (void)hipStreamDestroy(cs);
     srx_set_error("srx_graph_capture: hipStreamBeginCapture failed: %s", hipGetErrorString(e));
     return SRX_ERR_HIP;
   }
   const int rc = srx_run_ops(ops, n, cs);
   hipGraph_t g = nullptr;
   e = hipStreamEndCapture(cs, &g);
-  hipStreamDestroy(cs);
+  (void)hipStreamDestroy(cs);
   if (rc != SRX_OK) {
-    if (g) hipGraphDestroy(g);
+    if (g) (void)hipGraphDestroy(g);
     return rc;
   }
   if (e != hipSuccess || g == nullptr) {
@@ -125,7 +125,7 @@ int srx_graph_capture(const srx_op* ops, int n, void** graph_exec) {
   }
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess) {
     srx_set_error("srx_graph_capture: hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return SRX_ERR_HIP;

@@ -90,7 +90,6 @@ __device__ __forceinline__ void wgrad_stage_tile(const WgradParams& p, const T* 
                                                  int xbytes, int gbytes, const unsigned (&xoffs)[NXS],
                                                  const int (&xrc)[NXS], const unsigned (&goffs)[NGS],
                                                  const int (&grc)[NGS]) {
-  typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int TW = 1 << LTW, TH = TPIX >> LTW, PAD = KS / 2;
 
@@ -129,7 +128,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   typedef typename Frag<T>::type frag_t;
   constexpr int TW = 1 << LTW;
   constexpr int TH = TPIX >> LTW;
-  constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
   constexpr int IH = (TH - 1) * STRIDE + KS;
   constexpr int IW = (TW - 1) * STRIDE + KS;
@@ -248,8 +246,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   // whose offset is out of the descriptor's range deposits zeros in LDS (measured on gfx950),
   // which serves the zero padding, octets beyond the task's valid range and the pad slots:
   // no load is conditional and nothing passes through VGPRs.
-  typedef __attribute__((address_space(3))) void lds_void;
-  constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int XSL = 8 * PSX * PPO, GSL = 8 * PSG * PPO;       // slots per stage (incl. pads)
   constexpr int NXS = (XSL + 255) / 256, NGS = (GSL + 255) / 256;
   const unsigned xplane_b = (unsigned)(plane_x * sizeof(T)), gplane_b = (unsigned)(plane_g * sizeof(T));
