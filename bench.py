@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="replay recorded op lists as HIP graphs (0/1)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
+    ap.add_argument("--from-host", action="store_true",
+                    help="diagnostic: every step copies its batch from pinned host memory (PCIe-inclusive rate; "
+                         "not the headline value)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the gradient exchange over RCCL even with one rank")
     args = ap.parse_args()
@@ -232,12 +235,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.from_host:
+        lr_h, hr_h = lr.cpu().pin_memory(), hr.cpu().pin_memory()
+
+        def one_step():
+            trainer.step(lr_h.to(dev, non_blocking=True), hr_h.to(dev, non_blocking=True))
+    else:
+        def one_step():
+            trainer.step(lr, hr)
+
     for _ in range(args.warmup):
-        trainer.step(lr, hr)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(lr, hr)
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -254,7 +266,9 @@ def main():
         "metric": "LR Mpixels/sec ESRGAN 4x train step (fwd+bwd)", "value": round(value, 4),
         "unit": "LR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic" if not args.skip_wgrad else "INVALID: weight gradients skipped",
+        "vs_baseline": None, "dtype": "bf16", "data": ("INVALID: weight gradients skipped" if args.skip_wgrad else
+                                                              "synthetic, copied from pinned host memory every step" if args.from_host
+                                                              else "synthetic"),
         "config": {"workload": (f"config 3: adversarial step (D step + G step, 3 discriminator forwards, spectral "
                                 f"norm, VGG loss, Adam on both), batch {B}/GPU of {h}x{h} LR patches, bf16") if adv
                                else ({(16, 64): "config 2", (64, 128): "config 5 shape"}.get((B, h), "custom shape") +
