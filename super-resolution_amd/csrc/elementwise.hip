@@ -173,15 +173,29 @@ __global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
 }
 
 __global__ void unpack_wgrad_kernel(const srx_unpack_item* __restrict__ items) {
+  // source [tap][cout*cin] (tap-major staging), destination [cout*cin][tap] (nn.Conv2d layout).
+  // A thread owns one (cout, cin) pair: its `taps` reads are coalesced across the wave (one per tap
+  // plane), its writes are `taps` consecutive floats next to its neighbours'.
   const srx_unpack_item it = items[blockIdx.y];
-  const long n = (long)it.cout * it.cin * it.taps;
   const long plane = (long)it.cout * it.cin;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    // i indexes the destination [cout][cin][tap]
-    int tap = (int)(i % it.taps);
-    long oc = i / it.taps;
-    float v = it.src[tap * plane + oc];
-    it.dst[i] = it.accumulate ? it.dst[i] + v : v;
+  for (long oc = blockIdx.x * (long)blockDim.x + threadIdx.x; oc < plane; oc += (long)gridDim.x * blockDim.x) {
+    float* d = it.dst + oc * it.taps;
+    if (it.taps == 9) {
+      float v[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = it.src[t * plane + oc];
+      if (it.accumulate) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] += d[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) d[t] = v[t];
+    } else {
+      for (int t = 0; t < it.taps; ++t) {
+        const float v = it.src[t * plane + oc];
+        d[t] = it.accumulate ? d[t] + v : v;
+      }
+    }
   }
 }
 
@@ -649,7 +663,7 @@ int srx_pack_weights(int dtype, const srx_pack_layer* layers, const srx_pack_seg
 
 int srx_unpack_wgrad(const srx_unpack_item* items, int nitems, int64_t max_elems, void* stream) {
   SRX_CHECK_ARG(items && nitems > 0 && max_elems > 0, "srx_unpack_wgrad: bad argument");
-  dim3 grid(grid_for(max_elems, TPB, 64), nitems);
+  dim3 grid(grid_for(max_elems / 8, TPB, 64), nitems);     // max_elems counts taps too; a thread takes all taps of a pair
   hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(TPB), 0, STREAM, items);
   return srx_check_launch("unpack_wgrad");
 }
