@@ -19,35 +19,33 @@ from .. import chain
 from ..host import _SrxHost
 
 
+# (output channels, stride) of the eight 3x3 stages, in order (reference esrgan/discriminator.py:18-26)
+_STAGES = ((64, 1), (64, 2), (128, 1), (128, 2), (256, 1), (256, 2), (512, 1), (512, 2))
+_HEAD_WIDTH = 1024
+
+
 class Discriminator(_SrxHost):
-    """A VGG-style discriminator with spectral normalization."""
+    """Eight spectral-normalised 3x3 stages (four of them stride 2), global average pooling and a
+    two-layer 1x1 head producing one logit per image.
+
+    Module tree: ``features.{i}`` = Sequential(SN conv, LeakyReLU) for each stage,
+    ``classifier`` = Sequential(pool, SN conv, LeakyReLU, SN conv) — the key layout of the
+    reference's checkpoints.  Layers are created first to last, so the default initialisers and
+    the spectral-norm u/v draws consume the RNG in the reference's order."""
 
     def __init__(self, in_channels=3):
         super().__init__()
-
-        def conv_block(in_feat, out_feat, stride=1):
-            return nn.Sequential(
-                spectral_norm(nn.Conv2d(in_feat, out_feat, 3, stride=stride, padding=1)),
-                nn.LeakyReLU(0.2, inplace=True)
-            )
-
-        self.features = nn.Sequential(
-            conv_block(in_channels, 64),
-            conv_block(64, 64, stride=2),
-            conv_block(64, 128),
-            conv_block(128, 128, stride=2),
-            conv_block(128, 256),
-            conv_block(256, 256, stride=2),
-            conv_block(256, 512),
-            conv_block(512, 512, stride=2),
-        )
-
-        self.classifier = nn.Sequential(
-            nn.AdaptiveAvgPool2d(1),
-            spectral_norm(nn.Conv2d(512, 1024, 1)),
-            nn.LeakyReLU(0.2, inplace=True),
-            spectral_norm(nn.Conv2d(1024, 1, 1))
-        )
+        stages, width_in = [], in_channels
+        for width_out, stride in _STAGES:
+            conv = spectral_norm(nn.Conv2d(width_in, width_out, kernel_size=3, stride=stride, padding=1))
+            stages.append(nn.Sequential(conv, nn.LeakyReLU(0.2, inplace=True)))
+            width_in = width_out
+        self.features = nn.Sequential(*stages)
+        head = [nn.AdaptiveAvgPool2d(1)]
+        head.append(spectral_norm(nn.Conv2d(width_in, _HEAD_WIDTH, kernel_size=1)))
+        head.append(nn.LeakyReLU(0.2, inplace=True))
+        head.append(spectral_norm(nn.Conv2d(_HEAD_WIDTH, 1, kernel_size=1)))
+        self.classifier = nn.Sequential(*head)
 
     def _build_plan(self, params, B, h, w, tdtype, need_grad, need_input_grad):
         if h % 16 or w % 16:

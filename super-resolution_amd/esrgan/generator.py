@@ -26,11 +26,12 @@ class ResidualDenseBlock(_SrxHost):
 
     def __init__(self, in_channels=64, growth_channels=32):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_channels, growth_channels, 3, 1, 1)
-        self.conv2 = nn.Conv2d(in_channels + growth_channels, growth_channels, 3, 1, 1)
-        self.conv3 = nn.Conv2d(in_channels + 2 * growth_channels, growth_channels, 3, 1, 1)
-        self.conv4 = nn.Conv2d(in_channels + 3 * growth_channels, growth_channels, 3, 1, 1)
-        self.conv5 = nn.Conv2d(in_channels + 4 * growth_channels, in_channels, 3, 1, 1)
+        # conv k reads the block input and the k-1 growth slices before it; the fifth maps back to
+        # the block width.  Registered as conv1 .. conv5 (the checkpoint key names), in that order.
+        for k in range(1, 6):
+            width_in = in_channels + (k - 1) * growth_channels
+            width_out = growth_channels if k < 5 else in_channels
+            setattr(self, f"conv{k}", nn.Conv2d(width_in, width_out, kernel_size=3, stride=1, padding=1))
         self.lrelu = nn.LeakyReLU(0.2, inplace=True)
 
     def _build_plan(self, params, B, h, w, tdtype, need_grad, need_input_grad):
@@ -95,15 +96,19 @@ class GeneratorESRGAN(_SrxHost):
 
     def __init__(self, in_channels=3, out_channels=3, num_features=64, num_blocks=23):
         super().__init__()
-        self.conv_first = nn.Conv2d(in_channels, num_features, 3, 1, 1)
-        self.body = nn.Sequential(*[RRDB(num_features) for _ in range(num_blocks)])
-        self.conv_body = nn.Conv2d(num_features, num_features, 3, 1, 1)
+        nf = num_features
 
-        # Two upsampling blocks for 4x scale
-        self.upsample = nn.Sequential(UpsampleBlock(num_features), UpsampleBlock(num_features))
+        def conv3(width_in, width_out):
+            return nn.Conv2d(width_in, width_out, kernel_size=3, stride=1, padding=1)
 
-        self.conv_hr = nn.Conv2d(num_features, num_features, 3, 1, 1)
-        self.conv_last = nn.Conv2d(num_features, out_channels, 3, 1, 1)
+        # registration order = parameters() order = the reference's state_dict order:
+        # conv_first, body.{i}, conv_body, upsample.{0,1}, conv_hr, conv_last
+        self.conv_first = conv3(in_channels, nf)
+        self.body = nn.Sequential(*(RRDB(nf) for _ in range(num_blocks)))
+        self.conv_body = conv3(nf, nf)
+        self.upsample = nn.Sequential(*(UpsampleBlock(nf) for _ in range(2)))      # 2 x 2 = the 4x scale
+        self.conv_hr = conv3(nf, nf)
+        self.conv_last = conv3(nf, out_channels)
         self.lrelu = nn.LeakyReLU(0.2, inplace=True)
 
     def _build_plan(self, params, B, h, w, tdtype, need_grad, need_input_grad):
