@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="replay recorded op lists as HIP graphs (0/1)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
+    ap.add_argument("--adam-in-backward", type=int, default=0,
+                    help="single process: Adam applied range by range beside backward (0/1)")
     ap.add_argument("--from-host", action="store_true",
                     help="diagnostic: every step copies its batch from pinned host memory (PCIe-inclusive rate; "
                          "not the headline value)")
@@ -207,6 +209,8 @@ def main():
     if args.skip_wgrad:
         E.Plan.wgrad = lambda self, ops, *a, **k: None
     E.Plan.use_graphs = bool(args.graphs)
+    T.GeneratorWarmupTrainer.step_in_backward = bool(args.adam_in_backward)
+    T.AdversarialTrainer.step_in_backward = bool(args.adam_in_backward)
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
     if args.wgrad_slices is not None:
         E.GeneratorPlan.trunk_wgrad_slices = args.wgrad_slices

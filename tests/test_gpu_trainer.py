@@ -219,3 +219,26 @@ def test_flatten_parameters_is_idempotent():
     c = F.flatten_parameters(g)
     assert c.data_ptr() != a.data_ptr()
     assert next(g.parameters()).data_ptr() == c.data_ptr()
+
+
+def test_adam_applied_range_by_range_equals_one_launch():
+    """FlatAdam.step_range over the backward's segments (applied on the side stream beside backward)
+    is the same elementwise arithmetic as one launch after backward: the same parameters after three steps."""
+    T = pkg("train")
+    G = pkg("esrgan.generator")
+    lr = O.hash_input("rng.lr", (2, 3, 16, 16)).cuda()
+    hr = O.hash_input("rng.hr", (2, 3, 64, 64)).cuda()
+    outs = []
+    for flag in (False, True):
+        g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=11).cuda()
+        tr = T.GeneratorWarmupTrainer(g, (2, 3, 16, 16), torch.float32, lr=1e-3)
+        tr.step_in_backward = flag
+        for _ in range(3):
+            tr.step(lr, hr)
+        torch.cuda.synchronize()
+        assert tr.opt.step_count == 3
+        outs.append(torch.cat([p.detach().reshape(-1) for p in g.parameters()]).clone())
+    # (not bit-equal: the weight-gradient kernel sums its pixel slices with fp32 atomics, in whatever
+    #  order they arrive, in both runs alike)
+    d = (outs[0] - outs[1]).abs()
+    assert float(d.mean()) < 1e-6 and float((d > 1e-4).float().mean()) < 1e-3, (float(d.mean()), float(d.max()))
