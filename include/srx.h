@@ -154,6 +154,10 @@ typedef struct srx_wgrad_task {
   int32_t gy_oct;        /* first output-gradient octet plane (relative to gy view) */
   int32_t x_noct;        /* valid x octets from x_oct (<= 8)                        */
   int32_t gy_noct;       /* valid gy octets from gy_oct (<= 8)                      */
+  int32_t x_skip;        /* octet planes skipped between the task's first four x octets and its last
+                            four (0: eight consecutive planes): lets one task pair two 32-channel
+                            groups that are not neighbours in the buffer                         */
+  int32_t gy_skip;       /* the same for gy                                         */
   float* out[4];         /* [a + 2*b]: tap-major grad tensor base or NULL to skip   */
   int32_t ld[4];         /* Cin of that tensor                                      */
   int32_t co_n[4];       /* Cout of that tensor                                     */

@@ -10,6 +10,7 @@ torch.manual_seed(0)
 gen = G.GeneratorESRGAN(num_blocks=23).to(dev)
 params = {n: p.data for n, p in gen.named_parameters()}
 import os
+E.Plan.pair_wgrad_tasks = bool(int(os.environ.get('PAIR', '1')))
 E.GeneratorPlan.trunk_wgrad_slices = int(os.environ.get('SLICES', '4'))
 E.GeneratorPlan.trunk_wgrad_rdbs = int(os.environ.get('RDBS', '6'))
 plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, need_grad=True)

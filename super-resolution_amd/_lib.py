@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
 
 class WgradTask(C.Structure):
     _fields_ = [("x", vp), ("gy", vp), ("x_oct", i32), ("gy_oct", i32), ("x_noct", i32), ("gy_noct", i32),
-                ("out", vp * 4), ("ld", i32 * 4), ("co_n", i32 * 4), ("ci0", i32 * 4),
+                ("x_skip", i32), ("gy_skip", i32), ("out", vp * 4), ("ld", i32 * 4), ("co_n", i32 * 4), ("ci0", i32 * 4),
                 ("co0", i32 * 4), ("scale", f32 * 4),
                 ("bias_out", vp * 2), ("bias_co0", i32 * 2), ("bias_n", i32 * 2), ("bias_scale", f32 * 2)]
 

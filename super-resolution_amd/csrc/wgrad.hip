@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   float* const outp = tkp->out[sa + 2 * sb];
   float* const biasp = sa == 0 ? tkp->bias_out[sb] : nullptr;
   const int x_noct = tkp->x_noct, gy_noct = tkp->gy_noct;
+  const int x_skip = tkp->x_skip, gy_skip = tkp->gy_skip;      // planes between octets 3 and 4 of the task
   const bool active = outp != nullptr;          // wave-uniform
 
   const long plane_x = (long)p.H * p.W * 8;
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int XSL = 8 * PSX * PPO, GSL = 8 * PSG * PPO;       // slots per stage (incl. pads)
   constexpr int NXS = (XSL + 255) / 256, NGS = (GSL + 255) / 256;
   const unsigned xplane_b = (unsigned)(plane_x * sizeof(T)), gplane_b = (unsigned)(plane_g * sizeof(T));
-  const int xbytes = (int)((unsigned)x_noct * xplane_b), gbytes = (int)((unsigned)gy_noct * gplane_b);
+  const int xbytes = (int)((unsigned)(x_noct + (x_noct > 4 ? x_skip : 0)) * xplane_b);
+  const int gbytes = (int)((unsigned)(gy_noct + (gy_noct > 4 ? gy_skip : 0)) * gplane_b);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // per-slot constants: byte offset from the tile's first input pixel, and (row, col) for the
   // bounds test; rc < 0 marks a slot that always reads zeros
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int q = slot % PPO, pix = (slot / PPO) % PSX, o = slot / (PPO * PSX);
     int r = pix / IW, c = pix % IW;
     bool live = slot < XSL && pix < NPX && o < x_noct;
-    xoffs[i] = (unsigned)o * xplane_b + (unsigned)(((r * p.W + c) * 8 + q * EPP) * (int)sizeof(T));
+    xoffs[i] = (unsigned)(o + (o >= 4 ? x_skip : 0)) * xplane_b + (unsigned)(((r * p.W + c) * 8 + q * EPP) * (int)sizeof(T));
     xrc[i] = live ? (r | (c << 16)) : -1;
   }
 #pragma unroll
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int q = slot % PPO, pix = (slot / PPO) % PSG, o = slot / (PPO * PSG);
     int r = pix >> LTW, c = pix & (TW - 1);
     bool live = slot < GSL && pix < TPIX && o < gy_noct;
-    goffs[i] = (unsigned)o * gplane_b + (unsigned)(((r * p.OW + c) * 8 + q * EPP) * (int)sizeof(T));
+    goffs[i] = (unsigned)(o + (o >= 4 ? gy_skip : 0)) * gplane_b + (unsigned)(((r * p.OW + c) * 8 + q * EPP) * (int)sizeof(T));
     grc[i] = live ? (r | (c << 16)) : -1;
   }
   // tiles of this slice: a contiguous range, walked with (image, tile row, tile col) counters
@@ -427,9 +429,9 @@ extern "C" int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream) {
   SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->ntasks > 0 && d->nslices > 0,
                 "srx_conv2d_wgrad: non-positive size");
   SRX_CHECK_ARG(d->tasks, "srx_conv2d_wgrad: null task table");
-  // a task's 64 channels of one image are addressed through a 32-bit buffer descriptor with signed
-  // byte counts
-  SRX_CHECK_ARG((long)d->H * d->W * 64 * (d->dtype == SRX_BF16 ? 2 : 4) < (1L << 31),
+  // a task's channels of one image (64 of them, spread over at most 32 octet planes when the task
+  // pairs two distant groups) are addressed through a 32-bit buffer descriptor with signed byte counts
+  SRX_CHECK_ARG((long)d->H * d->W * 256 * (d->dtype == SRX_BF16 ? 2 : 4) < (1L << 31),
                 "srx_conv2d_wgrad: image of %d x %d is too large for one launch; tile the image", d->H, d->W);
   WgradParams p;
   p.x = d->x; p.x_is = d->x_img_stride;

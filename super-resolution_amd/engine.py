@@ -351,6 +351,52 @@ class Plan:
                 lst.append({**t, "sub": dict(t["sub"]), "bias": dict(t["bias"])})
         return [m for lst in merged.values() for m in lst]
 
+    # Off: with seven tasks per dense block instead of eight, the XCD-affine block order (all tasks of
+    # a block on one XCD, sharing its L2) packs 4 x 7 = 28 workgroups on an XCD's 32 CUs where it
+    # packed 4 x 8 = 32 — an eighth less work on an eighth fewer CUs, same time (measured: one
+    # pixel slice more per task overflows the XCD instead: 255 -> 403 us per launch).
+    pair_wgrad_tasks = False
+    MAX_TASK_SKIP = 24      # octet planes a task's two groups may lie apart (32 planes span in all)
+
+    @staticmethod
+    def pair_sparse_tasks(tasks: List[dict]) -> List[dict]:
+        """Two tasks that each keep ONE 32x32 sub-block busy (the odd 32-channel slices of a dense
+        block: y1 x gy2 of conv2, y3 x gy4 of conv4) become one task whose first four x / gy
+        octets are the first task's group and whose last four are the second's (x_skip / gy_skip
+        planes apart): sub-blocks (0,0) and (1,1) are used, the cross terms stay empty.  One
+        workgroup pass over the pixels less per pair."""
+        def single(t):
+            return len(t["sub"]) == 1 and not t["bias"] and not t.get("x_skip") and not t.get("gy_skip")
+
+        out, pool = [], []
+        for t in tasks:
+            (pool if single(t) else out).append(t)
+        pool.sort(key=lambda t: (t["x"], t["gy"], t["x_oct"] + 4 * (next(iter(t["sub"])) & 1)))
+        while pool:
+            t1 = pool.pop(0)
+            s1 = next(iter(t1["sub"]))
+            xg1, gg1 = t1["x_oct"] + 4 * (s1 & 1), t1["gy_oct"] + 4 * (s1 >> 1)
+            mate = None
+            for t2 in pool:
+                s2 = next(iter(t2["sub"]))
+                xg2, gg2 = t2["x_oct"] + 4 * (s2 & 1), t2["gy_oct"] + 4 * (s2 >> 1)
+                if (t2["x"], t2["gy"]) == (t1["x"], t1["gy"]) and 4 <= xg2 - xg1 <= 4 + Plan.MAX_TASK_SKIP \
+                        and 4 <= gg2 - gg1 <= 4 + Plan.MAX_TASK_SKIP:
+                    mate = (t2, s2, xg2, gg2)
+                    break
+            full1 = min(4, t1["x_noct"] - 4 * (s1 & 1)) == 4 and min(4, t1["gy_noct"] - 4 * (s1 >> 1)) == 4
+            if mate is None or not full1:
+                out.append(t1)
+                continue
+            t2, s2, xg2, gg2 = mate
+            pool.remove(t2)
+            out.append({"x": t1["x"], "gy": t1["gy"], "x_oct": xg1, "gy_oct": gg1,
+                        "x_noct": 4 + min(4, t2["x_noct"] - 4 * (s2 & 1)),
+                        "gy_noct": 4 + min(4, t2["gy_noct"] - 4 * (s2 >> 1)),
+                        "x_skip": xg2 - xg1 - 4, "gy_skip": gg2 - gg1 - 4,
+                        "sub": {0: t1["sub"][s1], 3: t2["sub"][s2]}, "bias": {}})
+        return out
+
     def wgrad(self, ops: list, x: Optional[View], gy: Optional[View], tasks: List[dict], B: int, H: int, W: int, *,
               ksize=3, stride=1, target_blocks=512, nslices: Optional[int] = None,
               x_img_stride: int = 0, gy_img_stride: int = 0, group: int = 0):
@@ -359,6 +405,7 @@ class Plan:
             k = arr[i]
             k.x, k.gy = (t.get("x") or None), (t.get("gy") or None)
             k.x_oct, k.gy_oct, k.x_noct, k.gy_noct = t["x_oct"], t["gy_oct"], t["x_noct"], t["gy_noct"]
+            k.x_skip, k.gy_skip = t.get("x_skip", 0), t.get("gy_skip", 0)
             for s, e in t["sub"].items():
                 k.out[s] = e["out"]
                 k.ld[s], k.co_n[s], k.ci0[s], k.co0[s], k.scale[s] = e["ld"], e["co_n"], e["ci0"], e["co0"], e["scale"]
@@ -677,7 +724,7 @@ class _GenBase(Plan):
             tasks += self.wgrad_tasks_for_layer(nf + (k - 1) * gc, gc if k < 5 else nf, 0, (k - 1) * gc8,
                                                 self.sp(pre + f"conv{k}.weight"), s5 if k == 5 else 1.0,
                                                 bias_ptr=self.sp(pre + f"conv{k}.bias"), x_ptr=xp, gy_ptr=gp)
-        tasks = self.merge_tasks(tasks)
+        tasks = self.pair_sparse_tasks(self.merge_tasks(tasks)) if self.pair_wgrad_tasks else self.merge_tasks(tasks)
         if defer_wgrad is not None:
             defer_wgrad.extend(tasks)
         else:

@@ -125,6 +125,14 @@ def test_wgrad_task_tables():
     # each conv's bias handled exactly once per 32-wide cout half
     biases = [(e["out"], e["co0"]) for t in merged for e in t["bias"].values()]
     assert sorted(biases) == sorted([(7001, 0), (7002, 0), (7003, 0), (7004, 0), (7005, 0), (7005, 32)])
+    # the two tasks with a single live sub-block (y1 x gy2 of conv2, y3 x gy4 of conv4) pair up
+    paired = E.Plan.pair_sparse_tasks(merged)
+    assert len(paired) == 7 and sum(len(t["sub"]) for t in paired) == 26
+    sp = [t for t in paired if t.get("x_skip") or t.get("gy_skip")]
+    assert len(sp) == 1 and sorted(sp[0]["sub"]) == [0, 3]
+    t = sp[0]      # x: y1 = octets 8..11, y3 = 16..19 ; gy: gy2 = 4..7, gy4 = 12..15
+    assert (t["x_oct"], t["x_skip"], t["x_noct"]) == (8, 4, 8) and (t["gy_oct"], t["gy_skip"], t["gy_noct"]) == (4, 4, 8)
+    assert (t["sub"][0]["out"], t["sub"][0]["ci0"]) == (2000, 64) and (t["sub"][3]["out"], t["sub"][3]["ci0"]) == (4000, 128)
     # ragged layer (Cin=3, Cout=64): one task, two sub-blocks (cin half 0 only)
     t = E.Plan.wgrad_tasks_for_layer(3, 64, 0, 0, 1)
     assert len(t) == 1 and sorted(t[0]["sub"]) == [0, 2] and t[0]["x_noct"] == 1

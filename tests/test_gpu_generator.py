@@ -175,3 +175,24 @@ def test_generator_with_pair_convolutions_matches_separate():
     assert rel_err(outs[1][0], outs[0][0]) < 2e-2
     cos = torch.nn.functional.cosine_similarity(outs[1][1], outs[0][1], dim=0)
     assert float(cos) > 0.99
+
+
+def test_paired_weight_gradient_tasks_give_the_same_gradients():
+    """Tasks that pair two distant 32-channel groups (x_skip / gy_skip of srx_wgrad_task) compute the
+    same weight gradients as the plain task list."""
+    E = pkg("engine")
+    G = pkg("esrgan.generator")
+    x = O.hash_input("pw.x", (2, 3, 16, 24)).cuda()
+    hr = O.hash_input("pw.hr", (2, 3, 64, 96)).cuda()
+    grads = []
+    for flag in (False, True):
+        E.Plan.pair_wgrad_tasks = flag
+        try:
+            g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=21).cuda()
+            loss = torch.nn.functional.l1_loss(g(x), hr)
+            loss.backward()
+            grads.append({n: p.grad.clone() for n, p in g.named_parameters()})
+        finally:
+            E.Plan.pair_wgrad_tasks = False
+    for n in grads[0]:
+        assert rel_err(grads[1][n], grads[0][n]) < 1e-5, n
