@@ -103,7 +103,10 @@ def cpu_baseline(iters=3):
         grads = torch.autograd.grad(loss, list(sd.values()))
         return grads
 
+    t0 = time.perf_counter()
     one()
+    warm = time.perf_counter() - t0
+    iters = max(iters, min(40, int(12.0 / max(warm, 1e-3))))      # about 12 s of CPU work in all
     t0 = time.perf_counter()
     for _ in range(iters):
         one()
