@@ -85,35 +85,117 @@ def profile_ops(plan, ctypes_mod):
     return stats
 
 
-def cpu_baseline(iters=3):
-    """Oracle (plain PyTorch fp32 restatement) of the same step on the host cores:
-    23-RRDB generator fwd + L1 + bwd on B=4 of 32x32 LR (BASELINE config 1 shape)."""
+def host_cpu_info():
+    """(model string, physical cores, logical CPUs) of the host, from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or None), (logical or os.cpu_count())
+
+
+def cpu_baseline():
+    """Oracle (plain PyTorch fp32 restatement of the reference) on the host cores, BASELINE
+    config 1's shape (B=4 of 32x32 LR, 23 blocks): the forward exactly as config 1 states it, and
+    the same train step the GPU line measures (fwd + L1 + bwd).  Bounded: about 6 s each.
+    Threads: the job's CPU share (OMP_NUM_THREADS, 16 per GPU on the measurement boxes), not
+    every core of the host — stated next to the host's core count."""
     from oracle import esrgan_oracle as O
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
-    torch.set_num_threads(cores)
+    model, physical, logical = host_cpu_info()
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = min(logical or 1, share) if share > 0 else (physical or logical or 1)
+    torch.set_num_threads(threads)
     sd = O.make_state_dict(O.generator_state_dict_spec(23), salt=3)
-    for v in sd.values():
-        v.requires_grad_(True)
     lr = O.hash_input("bench.lr", (4, 3, 32, 32))
     hr = O.hash_input("bench.hr", (4, 3, 128, 128))
 
-    def one():
-        out = O.generator_forward(lr, sd)
-        loss = O.l1_loss(out, hr)
-        grads = torch.autograd.grad(loss, list(sd.values()))
-        return grads
+    def fwd():
+        with torch.no_grad():
+            return O.generator_forward(lr, sd)
 
-    t0 = time.perf_counter()
-    one()
-    warm = time.perf_counter() - t0
-    iters = max(iters, min(40, int(12.0 / max(warm, 1e-3))))      # about 12 s of CPU work in all
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": 4 * 32 * 32 / dt / 1e6, "unit": "LR Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "oracle generator fwd+L1+bwd, fp32, B=4 of 32x32 LR (config-1 shape), "
-                      f"{iters} timed iters after 1 warm-up, {dt:.3f} s/iter"}
+    def fwd_bwd():
+        for v in sd.values():
+            v.requires_grad_(True)
+        out = O.generator_forward(lr, sd)
+        return torch.autograd.grad(O.l1_loss(out, hr), list(sd.values()))
+
+    def timed(fn, budget_s):
+        t0 = time.perf_counter()
+        fn()
+        warm = time.perf_counter() - t0
+        iters = max(3, min(40, int(budget_s / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) / iters, iters
+
+    dt_f, it_f = timed(fwd, 6.0)
+    dt_s, it_s = timed(fwd_bwd, 6.0)
+    px = 4 * 32 * 32
+    return {"value": px / dt_s / 1e6, "unit": "LR Mpixels/s", "cores": threads, "kind": "port",
+            "threads_used": threads, "host_physical_cores": physical, "host_logical_cpus": logical,
+            "cpu_model": model,
+            "forward_only_value": px / dt_f / 1e6,
+            "sample": "oracle generator, fp32, B=4 of 32x32 LR (config 1's shape), 23 blocks: value = fwd+L1+bwd "
+                      f"({it_s} timed iters after 1 warm-up, {dt_s:.3f} s/iter); forward_only_value = config 1 as "
+                      f"stated ({it_f} iters, {dt_f:.3f} s/iter); threads = OMP_NUM_THREADS (the job's CPU share)"}
+
+
+def child_commands(args_list, n, port):
+    """(argv, environment additions) of the n ranks this script starts itself for --gpus n when it
+    was not started by a launcher: one process per GPU, the same arguments, the rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    cmds = []
+    for r in range(n):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+        cmds.append(([sys.executable, os.path.abspath(__file__)] + list(args_list), env))
+    return cmds
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: start N fresh rank processes (before this process has made
+    any GPU call), forward rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    cmds = child_commands([a for a in argv if a != "--dry-launch"], args.gpus, port)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": [{"argv": c, "env": e} for c, e in cmds]}), flush=True)
+        return 0
+    ngpu = torch.cuda.device_count()            # counts devices without initialising the GPU
+    if ngpu < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {ngpu} GPU(s); one rank per GPU is "
+                         f"required (RCCL does not run two ranks on one device)")
+    procs = []
+    for r, (c, e) in enumerate(cmds):
+        procs.append(subprocess.Popen(c, env=dict(os.environ, **e),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0 if all(rc == 0 for rc in rcs) else 1
 
 
 def bench_inference(args, dev, rank, world):
@@ -177,9 +259,18 @@ def main():
                          "not the headline value)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the gradient exchange over RCCL even with one rank")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no launcher: print the rank commands instead of starting them")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0: a free one)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the ranks ourselves, before any GPU call here
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or let --gpus start them")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -197,6 +288,7 @@ def main():
         # shares one with the launch chain (normal) or the weight-gradient stream (low)
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        assert dist.get_world_size() == world
 
     import ctypes
     G = importlib.import_module("super-resolution_amd.esrgan.generator")
@@ -229,7 +321,7 @@ def main():
         disc = Dm.Discriminator().to(dev)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")            # synthetic VGG weights: there is no network
-            vgg = Lm.VGGLoss(device=dev)
+            vgg = Lm.VGGLoss(device=dev, allow_synthetic=True)
         sync_d = D.FlatGradAllReduce(world, single_rank_too=True) if exchange else None
         trainer = T.AdversarialTrainer(gen, disc, vgg, (B, 3, h, h), torch.bfloat16, grad_sync_g=sync,
                                        grad_sync_d=sync_d)
@@ -257,11 +349,18 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
+    # device events between the steps (on the launch stream, where every step begins and ends):
+    # the per-step median next to the wall-clock mean the headline value is computed from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         one_step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +374,9 @@ def main():
     out = {
         "metric": "LR Mpixels/sec ESRGAN 4x train step (fwd+bwd)", "value": round(value, 4),
         "unit": "LR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median_events": round(median_ms, 3),
+        "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": ("INVALID: weight gradients skipped" if args.skip_wgrad else
                                                               "synthetic, copied from pinned host memory every step" if args.from_host
                                                               else "synthetic"),

@@ -24,6 +24,7 @@ from typing import Callable, Dict, Iterable, List, Optional
 import torch
 
 from .. import train as T
+from ..parallel import barrier
 from ..utils import checkpointing as ckpt
 from ..validate import Validator
 
@@ -92,6 +93,7 @@ def fit(gen, disc, vgg_loss, train_loader: Iterable, val_loader: Iterable, check
     adv = T.AdversarialTrainer(gen, disc, vgg_loss, batch_shape, compute_dtype, lr=lr, lambda_l1=lambda_l1,
                                lambda_adv=lambda_adv, lambda_percep=lambda_percep,
                                grad_sync_g=grad_sync_g, grad_sync_d=grad_sync_d)
+    log(f"--- Perceptual loss: VGG19 weights from {getattr(vgg_loss, 'weights_source', 'unknown')} ---")
     start_epoch, best_psnr = 0, 0.0
     if resume:
         start_epoch, best_psnr = ckpt.load_latest_training_checkpoint(cdir, gen, disc, adv.opt_g, adv.opt_d)
@@ -106,8 +108,10 @@ def fit(gen, disc, vgg_loss, train_loader: Iterable, val_loader: Iterable, check
             log(f"Pre-train epoch {epoch + 1} | L1: {l1:.5f}")
             ckpt.save_generator(gen, pretrained)
         del warm
+        barrier()                     # rank 0's file is complete before any rank tests for it or reads it
         log(f"--- Pre-training Finished. Model saved to '{pretrained}' ---")
 
+    barrier()
     if mode in ("train", "all") and start_epoch == 0 and pretrained.exists():
         log(f"--- Loading pre-trained generator from {pretrained} ---")
         ckpt.load_generator(gen, pretrained)

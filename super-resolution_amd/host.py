@@ -19,6 +19,36 @@ def _auto_compute_dtype(module: nn.Module, x: torch.Tensor) -> torch.dtype:
     return torch.float32
 
 
+class ParamTracker:
+    """name -> fp32 tensor whose storage a module's plans read, kept current.
+
+    Plans hold raw pointers into these tensors.  ``module.to()`` / ``.half()`` and
+    ``flatten_parameters`` (building a trainer) give the parameters new storage; the pointer
+    signature taken at every call notices that, and ``changed`` then tells the owner to drop its
+    plans.  fp32 parameters are used in place (in-place optimizer updates are seen by the next
+    weight packing); low-precision parameters are mirrored into fp32 copies refreshed per call."""
+
+    def __init__(self):
+        self.sig = None
+        self.p32: Optional[Dict[str, torch.Tensor]] = None
+
+    def current(self, module: nn.Module):
+        """Returns (params, changed)."""
+        named = list(module.named_parameters())
+        sig = tuple(p.data_ptr() for _, p in named) + tuple(b.data_ptr() for b in module.buffers())
+        changed = sig != self.sig
+        if changed:
+            self.sig, self.p32 = sig, None
+        if all(p.dtype == torch.float32 for _, p in named):
+            self.p32 = {n: p.data for n, p in named}
+        elif self.p32 is None:
+            self.p32 = {n: p.data.float().contiguous() for n, p in named}
+        else:
+            for n, p in named:
+                self.p32[n].copy_(p.data)
+        return self.p32, changed
+
+
 class _PlanFn(torch.autograd.Function):
     """Autograd node for one plan execution (whole module forward/backward)."""
 
@@ -63,7 +93,7 @@ class _SrxHost(nn.Module):
     def _srx_state(self) -> dict:
         st = self.__dict__.get("_srx")
         if st is None:
-            st = {"plans": {}, "p32": None, "sig": None}
+            st = {"plans": {}, "tracker": ParamTracker()}
             self.__dict__["_srx"] = st
         return st
 
@@ -78,21 +108,10 @@ class _SrxHost(nn.Module):
         """name -> fp32 tensor whose storage the plans read.  fp32 parameters are used in
         place; low-precision parameters are mirrored into fp32 copies refreshed per forward."""
         st = self._srx_state()
-        named = list(self.named_parameters())
-        sig = tuple(p.data_ptr() for _, p in named) + tuple(b.data_ptr() for b in self.buffers())
-        if st["sig"] != sig:
+        params, changed = st["tracker"].current(self)
+        if changed:
             st["plans"].clear()
-            st["sig"] = sig
-            st["p32"] = None
-        if all(p.dtype == torch.float32 for _, p in named):
-            st["p32"] = {n: p.data for n, p in named}
-        else:
-            if st["p32"] is None:
-                st["p32"] = {n: p.data.float().contiguous() for n, p in named}
-            else:
-                for n, p in named:
-                    st["p32"][n].copy_(p.data)
-        return st["p32"]
+        return params
 
     def _acquire_plan(self, x: torch.Tensor, need_grad: bool, need_input_grad: bool):
         if x.device.type != "cuda":

@@ -21,6 +21,7 @@ import torch
 
 from . import _lib as L
 from . import engine
+from .host import ParamTracker
 
 SCALE = 4
 
@@ -79,18 +80,19 @@ class SuperResolutionInference:
         self.tile_batch = max(1, int(tile_batch))
         self.window_kind = window
         self._plans: Dict[Tuple[int, int, int], engine.GeneratorPlan] = {}
-        self._params: Optional[Dict[str, torch.Tensor]] = None
+        self._tracker = ParamTracker()
         self._windows: Dict[int, torch.Tensor] = {}
         self.lib = L.lib()
 
     # ------------------------------------------------------------------ plans
     def _plan(self, B: int, h: int, w: int) -> engine.GeneratorPlan:
         g = self.model
-        if self._params is None:
-            # fp32 master copies the plans read (weights are re-packed from them every forward, so
-            # in-place updates of fp32 parameters are picked up)
-            self._params = {n: (p.data if p.dtype == torch.float32 else p.data.float())
-                            for n, p in g.named_parameters()}
+        # fp32 master copies the plans read (weights are re-packed from them every forward, so
+        # in-place updates of fp32 parameters are picked up); parameters that moved to new storage
+        # (model.to() / .half(), a trainer's flatten_parameters) invalidate the plans
+        self._params, moved = self._tracker.current(g)
+        if moved:
+            self._plans.clear()
         key = (B, h, w)
         plan = self._plans.get(key)
         if plan is None:

@@ -19,9 +19,41 @@ def _host_staged_sum(t: torch.Tensor, group) -> None:
     """Sum a device tensor over a gloo group through a host copy.  Only rehearsals of the
     multi-rank path on a single GPU come here (RCCL needs one GPU per rank); gloo's own
     device-tensor collectives stall intermittently when two ranks share one GPU."""
+    # every kernel that produces t has finished before the copy is queued: with three processes on
+    # the card (two ranks and the test runner) a device-to-host copy queued behind cross-stream
+    # event waits was seen to stall for tens of seconds
+    torch.cuda.synchronize(t.device)
     h = t.detach().cpu()
     dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     t.copy_(h)
+
+
+def _multi_rank(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def broadcast_from_rank0(tensors, group=None) -> None:
+    """Make every rank's copy of the given tensors (flat parameter buffers, spectral-norm u / v)
+    equal to rank 0's.  Data-parallel training is only correct while the replicas hold the same
+    parameters; building the models from the same seed on every rank gives that too, and this
+    makes it hold by construction.  No-op without a process group or with one rank."""
+    if not _multi_rank(group):
+        return
+    staged = dist.get_backend(group) != "nccl"
+    for t in tensors:
+        if t.is_cuda and staged:                    # gloo rehearsal with device tensors
+            h = t.detach().cpu()
+            dist.broadcast(h, src=0, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=0, group=group)
+
+
+def barrier(group=None) -> None:
+    """Every rank waits here (a file rank 0 has just written is complete before any rank reads
+    it).  No-op without a process group or with one rank."""
+    if _multi_rank(group):
+        dist.barrier(group=group)
 
 
 class FlatGradAllReduce:

@@ -16,6 +16,7 @@ import torch
 
 from . import _lib as L
 from . import chain, engine
+from .parallel import broadcast_from_rank0
 from .utils.flat import flatten_parameters
 
 
@@ -35,6 +36,10 @@ class FlatAdam:
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # the learning rate the schedule starts from: torch's schedulers keep it in the parameter
+        # group as 'initial_lr', and CosineAnnealingLR(last_epoch=start_epoch-1) — how the reference
+        # resumes, esrgan/train_esrgan.py:159-160 — refuses a loaded group without it
+        self.initial_lr = lr
         self.step_count = 0
         # per-parameter shapes in parameters() order: what state_dict() needs to speak
         # torch.optim.Adam's format (which indexes parameters by position)
@@ -52,7 +57,8 @@ class FlatAdam:
                             "exp_avg": self.m[off:off + n].view(shp).clone(),
                             "exp_avg_sq": self.v[off:off + n].view(shp).clone()}
                 off += n
-        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+        group = {"lr": self.lr, "initial_lr": self.initial_lr, "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.wd,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                  "differentiable": False, "fused": None, "decoupled_weight_decay": False,
                  "params": list(range(len(self.shapes)))}
@@ -68,6 +74,7 @@ class FlatAdam:
         g = groups[0]
         self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
         self.wd = g.get("weight_decay", 0.0)
+        self.initial_lr = g.get("initial_lr", self.initial_lr)
         self.m.zero_()
         self.v.zero_()
         steps, off = set(), 0
@@ -104,6 +111,18 @@ class FlatAdam:
                                  self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo, hi - lo, self.lr,
                                  self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
                                  engine.stream_ptr(self.p.device)), "srx_adam")
+
+
+def _checked_batch(lr_img: torch.Tensor, hr_img: torch.Tensor, lr_shape, hr_shape, device):
+    """The kernels read the batch through raw pointers as contiguous fp32 of the shapes the plans
+    were built for: anything else (another dtype, size or device) would be read as garbage or out
+    of bounds, so it is converted or rejected here."""
+    for name, t, shp in (("lr", lr_img, lr_shape), ("hr", hr_img, hr_shape)):
+        if tuple(t.shape) != tuple(shp):
+            raise ValueError(f"{name} batch has shape {tuple(t.shape)}, the trainer was built for {tuple(shp)}")
+        if t.device != device:
+            raise ValueError(f"{name} batch is on {t.device}, the trainer runs on {device}")
+    return lr_img.float().contiguous(), hr_img.float().contiguous()
 
 
 def _backward_with_exchange(plan, grad_sync) -> bool:
@@ -154,6 +173,8 @@ class GeneratorWarmupTrainer:
             n_streams = 1
         self.gen = gen
         self.flat = flatten_parameters(gen)
+        if grad_sync is not None:
+            broadcast_from_rank0([self.flat], getattr(grad_sync, "group", None))
         params = {n: p.data for n, p in gen.named_parameters()}
         dev = self.flat.device
         kw = dict(in_ch=gen.conv_first.in_channels, out_ch=gen.conv_last.out_channels,
@@ -173,6 +194,8 @@ class GeneratorWarmupTrainer:
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self.grad_sync = grad_sync
         self.steps = 0
+        self._lr_shape = (B, kw["in_ch"], h, w)
+        self._hr_shape = (B, kw["out_ch"], 4 * h, 4 * w)
 
     # single process: Adam applied range by range beside the rest of backward instead of one launch
     # after it.  Same arithmetic; measured 0.6-1 % slower (the extra short launches sit between the
@@ -192,8 +215,7 @@ class GeneratorWarmupTrainer:
         return False
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
-        hr_img = hr_img.contiguous()
-        lr_img = lr_img.contiguous()
+        lr_img, hr_img = _checked_batch(lr_img, hr_img, self._lr_shape, self._hr_shape, self.flat.device)
         exchanged = False
         if self.n_streams == 1:
             exchanged = self._sub_step(self.plan, lr_img, hr_img)
@@ -258,6 +280,11 @@ class AdversarialTrainer:
         self.lams = (lambda_l1, lambda_adv, lambda_percep)
         self.flat_g = flatten_parameters(gen)
         self.flat_d = flatten_parameters(disc)
+        if grad_sync_g is not None or grad_sync_d is not None:
+            # replicas start from rank 0's generator, discriminator and spectral-norm u / v (which
+            # then evolve identically on every rank and are never communicated again)
+            grp = getattr(grad_sync_g if grad_sync_g is not None else grad_sync_d, "group", None)
+            broadcast_from_rank0([self.flat_g, self.flat_d] + [b for b in disc.buffers()], grp)
         dev = self.flat_g.device
         self.device = dev
         gparams = {n: p.data for n, p in gen.named_parameters()}
@@ -321,8 +348,9 @@ class AdversarialTrainer:
         vf.backward_c8()
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> None:
-        lr_img, hr_img = lr_img.contiguous(), hr_img.contiguous()
         gp, lib = self.gplan, self.gplan.lib
+        lr_img, hr_img = _checked_batch(lr_img, hr_img, (gp.B, gp.in_ch, gp.h, gp.w),
+                                        (gp.B, gp.out_ch, 4 * gp.h, 4 * gp.w), self.device)
         sp = engine.stream_ptr(self.device)
         l_l1, l_adv, l_percep = self.lams
         vf, vr = self.v_fake, self.v_real

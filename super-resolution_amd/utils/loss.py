@@ -4,9 +4,11 @@ and the data gradient back to the first argument.
 
 Weights: the reference downloads torchvision's ``IMAGENET1K_V1`` checkpoint.  There is no
 network here, so the constructor looks for a local torchvision-format state_dict
-(``SRX_VGG19_WEIGHTS`` or ``~/.cache/torch/hub/checkpoints/vgg19-dcbb9e9d.pth``) and, if
-none is found, uses seeded synthetic weights and says so.  Like the reference, no ImageNet
-mean/std normalisation is applied to the inputs.
+(``SRX_VGG19_WEIGHTS`` or ``~/.cache/torch/hub/checkpoints/vgg19-dcbb9e9d.pth``) and raises
+``FileNotFoundError`` if none is found: training against any other weights optimises a different
+perceptual objective.  ``VGGLoss(allow_synthetic=True)`` (tests, benchmarks) falls back to seeded
+synthetic weights instead and says so; ``weights_source`` records which were used.  Like the
+reference, no ImageNet mean/std normalisation is applied to the inputs.
 """
 from __future__ import annotations
 
@@ -37,27 +39,28 @@ def build_vgg19_features36() -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-def _load_local_weights(vgg: nn.Sequential) -> bool:
+def _load_local_weights(vgg: nn.Sequential) -> Optional[str]:
+    """Load a torchvision-format VGG19 state_dict if one is present; returns its path or None."""
     path = os.environ.get("SRX_VGG19_WEIGHTS") or (_HUB if os.path.exists(_HUB) else None)
     if not path:
-        return False
+        return None
     sd = torch.load(path, map_location="cpu", weights_only=True)
     sd = {k[len("features."):]: v for k, v in sd.items() if k.startswith("features.")} or sd
     vgg.load_state_dict({k: v for k, v in sd.items() if k.split(".")[0].isdigit() and int(k.split(".")[0]) < 36})
-    return True
+    return path
 
 
 class _VGGLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fake, real, anchor, host):
-        loss = host._forward_impl(fake, real, need_grad=fake.requires_grad)
-        ctx.host = host
+        loss, plan = host._forward_impl(fake, real, need_grad=fake.requires_grad)
+        ctx.host, ctx.plan, ctx.version = host, plan, plan.version
         ctx.in_dtype = fake.dtype
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        return ctx.host._backward_impl(gloss).to(ctx.in_dtype), None, None, None
+        return ctx.host._backward_impl(ctx.plan, ctx.version, gloss).to(ctx.in_dtype), None, None, None
 
 
 class VGGLoss(nn.Module):
@@ -68,10 +71,17 @@ class VGGLoss(nn.Module):
 
     compute_dtype: Optional[torch.dtype] = None
 
-    def __init__(self, device=None, seed: int = 0):
+    def __init__(self, device=None, seed: int = 0, allow_synthetic: bool = False):
         super().__init__()
         vgg = build_vgg19_features36().eval()
-        if not _load_local_weights(vgg):
+        path = _load_local_weights(vgg)
+        self.weights_source = path or "synthetic (seed %d)" % seed
+        if path is None:
+            if not allow_synthetic:
+                raise FileNotFoundError(
+                    "VGGLoss: no VGG19 ImageNet checkpoint found.  Point SRX_VGG19_WEIGHTS at a torchvision "
+                    "vgg19-dcbb9e9d.pth state_dict (or place it at %s).  VGGLoss(allow_synthetic=True) uses "
+                    "seeded random weights instead: fine for tests and benchmarks, not for training." % _HUB)
             warnings.warn("VGGLoss: no local VGG19 checkpoint found (set SRX_VGG19_WEIGHTS); using seeded "
                           "synthetic weights", stacklevel=2)
             g = torch.Generator().manual_seed(seed)
@@ -103,6 +113,7 @@ class VGGLoss(nn.Module):
             pf = chain.VGGFeaturePlan(params, B, H, W, tdtype, need_input_grad=need_grad)
             pr = chain.VGGFeaturePlan(params, B, H, W, tdtype, need_input_grad=False)
             loss_buf = torch.zeros(1, dtype=torch.float32, device=x.device)
+            pf.version = 0
             plans[key] = (pf, pr, loss_buf, params)
             pf.run_packing()
             pr.run_packing()          # frozen weights: packed once
@@ -112,7 +123,7 @@ class VGGLoss(nn.Module):
         if fake.device.type != "cuda":
             raise RuntimeError("VGGLoss runs on a ROCm GPU only: the HIP extension is the only implementation")
         pf, pr, loss_buf, _ = self._get_plans(fake, need_grad)
-        self._cur = (pf, pr, loss_buf)
+        pf.version += 1
         fa = pf.forward_c8(fake, pack=False)
         fb = pr.forward_c8(real.detach(), pack=False)
         loss_buf.zero_()
@@ -121,10 +132,12 @@ class VGGLoss(nn.Module):
         L.check(pf.lib.srx_l1_c8(pf.dt, fa.ptr(), fa.img_stride, fb.ptr(), fb.img_stride, loss_buf.data_ptr(),
                                  g.ptr() if g is not None else None, g.img_stride if g is not None else 0,
                                  1.0, 0.0, B, C_, H, W, stream_ptr(pf.device)), "srx_l1_c8")
-        return loss_buf[0].clone()
+        return loss_buf[0].clone(), pf
 
-    def _backward_impl(self, gloss: torch.Tensor) -> torch.Tensor:
-        pf, _, _ = self._cur
+    def _backward_impl(self, pf, version: int, gloss: torch.Tensor) -> torch.Tensor:
+        if pf.version != version:
+            raise RuntimeError("VGGLoss: the activations saved for this backward were overwritten by a later "
+                               "forward of the same shape (one un-backpropagated forward per shape at a time)")
         pf.backward_c8()
         return pf.c8_to_nchw((pf.gA[0], 0), 3) * gloss
 
@@ -132,4 +145,4 @@ class VGGLoss(nn.Module):
         if torch.is_grad_enabled() and input_features.requires_grad:
             anchor = torch.empty(0, device=input_features.device, requires_grad=True)
             return _VGGLossFn.apply(input_features, target_features, anchor, self)
-        return self._forward_impl(input_features, target_features, need_grad=False)
+        return self._forward_impl(input_features, target_features, need_grad=False)[0]

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import engine
+from .host import ParamTracker
 
 SCALE = 4
 
@@ -25,13 +26,15 @@ class Validator:
         self.gen = gen
         self.tdtype = compute_dtype
         self._plans: Dict[Tuple[int, int, int], engine.GeneratorPlan] = {}
-        self._params = None
+        self._tracker = ParamTracker()
 
     def _plan(self, B, h, w):
         g = self.gen
-        if self._params is None:
-            self._params = {n: (p.data if p.dtype == torch.float32 else p.data.float())
-                            for n, p in g.named_parameters()}
+        # a trainer built after this object (flatten_parameters), gen.to() or gen.half() move the
+        # parameters to new storage: plans that point at the old one are dropped
+        self._params, moved = self._tracker.current(g)
+        if moved:
+            self._plans.clear()
         key = (B, h, w)
         if key not in self._plans:
             self._plans[key] = engine.GeneratorPlan(

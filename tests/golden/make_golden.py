@@ -53,12 +53,32 @@ def grad_summary(named_params):
     return out
 
 
+def full_grads(case_name, named_params, names, steps=None):
+    """Whole gradient tensors of the named parameters (every `steps[name]`-th flat element for
+    the few large ones), stored as `<case>_grad::<name>`: element-wise evidence that a
+    permutation of rows or taps inside a tensor cannot pass."""
+    steps = steps or {}
+    P = dict(named_params)
+    index = {}
+    for n in names:
+        g = P[n].grad.detach().float()
+        st = steps.get(n, 1)
+        key = f"{case_name}_grad::{n}"
+        arrays[key] = (g.flatten()[::st] if st > 1 else g).numpy().copy()
+        index[n] = {"array": key, "step": st}
+    return index
+
+
 def sample(t, step):
     return t.detach().flatten()[::step].float().numpy().copy()
 
 
 manifest = {"filler": "oracle.esrgan_oracle.hash_uniform / fill_state_dict_", "cases": {}}
 arrays = {}
+
+BLOCK_FULL = {"rdb": ["conv1.weight", "conv3.bias", "conv5.weight"],
+              "rrdb": ["rdb1.conv2.weight", "rdb2.conv1.weight", "rdb3.conv5.weight", "rdb3.conv5.bias"],
+              "upsample": ["conv.weight", "conv.bias"]}
 
 
 def case(name, **kw):
@@ -90,7 +110,8 @@ for name, mod, shape in (("rdb", ResidualDenseBlock(64, 32), (2, 64, 12, 20)),
     arrays[name + "_gx"] = xin.grad.numpy()
     case(name, x=f"hash_input('{name}.x', {list(shape)})", gy=f"hash_input('{name}.gy', y.shape)",
          loss="sum(y*gy)", salt=1, y=name + "_y", gx=name + "_gx",
-         grads=grad_summary(mod.named_parameters()), pinned_by="reference")
+         grads=grad_summary(mod.named_parameters()),
+         full_grads=full_grads(name, mod.named_parameters(), BLOCK_FULL[name]), pinned_by="reference")
 
 # ---------------------------------------------------------------- generator, 1 block, small
 g1 = fill_module_(GeneratorESRGAN(num_blocks=1), salt=2)
@@ -105,7 +126,13 @@ arrays["g1_out"] = out.detach().numpy()
 arrays["g1_glr"] = lr.grad.numpy()
 case("g1", num_blocks=1, lr="hash_input('g1.lr',[2,3,16,24])", hr="hash_input('g1.hr',[2,3,64,96])",
      salt=2, loss="L1Loss(out,hr)", loss_value=float(loss), out="g1_out", glr="g1_glr",
-     grads=grad_summary(g1.named_parameters()), pinned_by="reference")
+     grads=grad_summary(g1.named_parameters()),
+     full_grads=full_grads("g1", g1.named_parameters(),
+                           ["conv_first.weight", "conv_first.bias", "body.0.rdb1.conv1.weight",
+                            "body.0.rdb2.conv4.weight", "body.0.rdb3.conv5.weight", "conv_body.weight",
+                            "upsample.0.conv.weight", "upsample.1.conv.weight", "upsample.1.conv.bias",
+                            "conv_hr.weight", "conv_last.weight", "conv_last.bias"]),
+     pinned_by="reference")
 
 # ---------------------------------------------------------------- generator, 23 blocks, config 1
 g23 = fill_module_(GeneratorESRGAN(), salt=3)
@@ -122,7 +149,13 @@ arrays["g23_out_s7"] = sample(out, 7)
 case("g23", num_blocks=23, lr="hash_input('g23.lr',[4,3,32,32])", hr="hash_input('g23.hr',[4,3,128,128])",
      salt=3, loss="L1Loss(out,hr)", loss_value=float(loss), out_sample="g23_out_s7", sample_step=7,
      out_sum=float(out.double().sum()), out_abs_sum=float(out.double().abs().sum()),
-     grads=grad_summary(g23.named_parameters()), pinned_by="reference")
+     grads=grad_summary(g23.named_parameters()),
+     full_grads=full_grads("g23", g23.named_parameters(),
+                           ["conv_first.weight", "body.0.rdb1.conv1.weight", "body.11.rdb2.conv3.weight",
+                            "body.22.rdb3.conv5.weight", "body.22.rdb3.conv5.bias", "conv_body.weight",
+                            "upsample.1.conv.weight", "conv_last.weight"],
+                           steps={"upsample.1.conv.weight": 4}),
+     pinned_by="reference")
 manifest["g_state_dict"] = [[k, list(v.shape), str(v.dtype)] for k, v in g23.state_dict().items()]
 manifest["g_num_params"] = sum(p.numel() for p in g23.parameters())
 spec = O.generator_state_dict_spec(23)
@@ -168,6 +201,11 @@ for k in ("features.0.0", "features.7.0", "classifier.1", "classifier.3"):
         assert (ref - state[f"{k}.{s}"]).abs().max().item() < 1e-6
         arrays[f"d_after2_{k}.{s}"] = ref.numpy().copy()
 dgr = grad_summary(d.named_parameters())
+dfull = full_grads("d", d.named_parameters(),
+                   ["features.0.0.weight_orig", "features.0.0.bias", "features.3.0.weight_orig",
+                    "features.6.0.weight_orig", "classifier.1.weight_orig", "classifier.1.bias",
+                    "classifier.3.weight_orig"],
+                   steps={"features.6.0.weight_orig": 16, "classifier.1.weight_orig": 8})
 # third train-mode forward (G step) and an eval forward
 l3 = d(xf.detach())
 arrays["d_logits_third"] = l3.detach().numpy()
@@ -180,7 +218,7 @@ case("d", salt=4, real="hash_input('d.real',[2,3,64,64])", fake="hash_input('d.f
      loss="(BCE(D(real),1)+BCE(D(fake),0))/2", loss_value=float(loss_d),
      logits_real="d_logits_real", logits_fake="d_logits_fake", gx_fake="d_gx_fake",
      logits_third="d_logits_third", logits_eval="d_logits_eval",
-     grads=dgr, pinned_by="reference")
+     grads=dgr, full_grads=dfull, pinned_by="reference")
 
 # 128x128 logits (reference default HR crop, config.py:40)
 fill_module_(d, salt=4)
@@ -216,6 +254,8 @@ loss_disc = (bce(disc_real, torch.ones_like(disc_real)) + bce(disc_fake, torch.z
 d.zero_grad(set_to_none=True)
 loss_disc.backward()
 d_grads = grad_summary(d.named_parameters())
+d_full = full_grads("adv_d", d.named_parameters(), ["features.0.0.weight_orig", "features.2.0.weight_orig",
+                                                    "classifier.3.weight_orig"])
 # (no optimizer step between the phases: the fixture pins the loss graph, not Adam)
 disc_fake_for_gen = d(fake)
 gen_adv = bce(disc_fake_for_gen, torch.ones_like(disc_fake_for_gen))
@@ -225,13 +265,15 @@ loss_gen = 1.0 * gen_l1 + 5e-3 * gen_adv + 1.0 * gen_vgg
 g.zero_grad(set_to_none=True)
 loss_gen.backward()
 g_grads = grad_summary(g.named_parameters())
+g_full = full_grads("adv_g", g.named_parameters(), ["conv_first.weight", "body.1.rdb3.conv5.weight",
+                                                    "upsample.0.conv.weight", "conv_last.weight"])
 arrays["adv_fake_s5"] = sample(fake, 5)
 case("adv_step", g_blocks=2, g_salt=5, d_salt=6, vgg_salt=7, vgg_gain=1.4,
      lr="hash_input('adv.lr',[2,3,16,16])", hr="hash_input('adv.hr',[2,3,64,64])",
      lambdas=[1.0, 5e-3, 1.0],
      loss_disc=float(loss_disc), gen_adv_loss=float(gen_adv), gen_l1_loss=float(gen_l1),
      gen_vgg_loss=float(gen_vgg), loss_gen=float(loss_gen), fake_sample="adv_fake_s5", sample_step=5,
-     d_grads=d_grads, g_grads=g_grads,
+     d_grads=d_grads, g_grads=g_grads, d_full_grads=d_full, g_full_grads=g_full,
      pinned_by="reference G and D; VGG features by the oracle (synthetic weights)")
 
 # oracle VGG-only fixture

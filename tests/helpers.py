@@ -48,6 +48,23 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
 TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
 
 
+def full_grads_bad(named_grads, index, arr, tol):
+    """Element-wise comparison of whole gradient tensors against the reference's (the
+    `full_grads` index of a golden case): returns [(name, rel L2, rel max)] of the tensors whose
+    relative L2 error exceeds tol or whose max-norm error exceeds 4*tol."""
+    grads = dict(named_grads)
+    bad = []
+    assert index, "the golden case holds no full gradient tensors"
+    for n, ent in index.items():
+        g = grads[n].detach().float().cpu().flatten()[::ent["step"]]
+        ref = torch.from_numpy(arr[ent["array"]]).flatten()
+        assert g.shape == ref.shape, (n, g.shape, ref.shape)
+        e2, em = rel_l2(g, ref), rel_err(g, ref)
+        if not (e2 < tol and em < 4 * tol):
+            bad.append((n, e2, em))
+    return bad
+
+
 def fill_module_(m, salt=0, gain=1.0):
     sd = m.state_dict()
     O.fill_state_dict_(sd, salt, gain)

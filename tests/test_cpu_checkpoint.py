@@ -50,6 +50,37 @@ def test_flat_adam_state_dict_is_torch_adam_layout():
     assert T.FlatAdam(flat, shapes=[p.shape for p in m2.parameters()]).state_dict()["state"] == {}
 
 
+def test_flat_adam_state_resumes_in_the_reference_trainer():
+    """The reference's resume (esrgan/train_esrgan.py:151-160): opt.load_state_dict(checkpoint state),
+    then CosineAnnealingLR(opt, T_max, eta_min, last_epoch=start_epoch-1) — which raises KeyError
+    unless the loaded parameter group carries 'initial_lr'."""
+    T = pkg("train")
+    F = pkg("utils.flat")
+    m = nn.Sequential(nn.Linear(5, 4), nn.Linear(4, 3))
+    flat = F.flatten_parameters(m)
+    fa = T.FlatAdam(flat, lr=2e-4, shapes=[p.shape for p in m.parameters()])
+    fa.lr = T.cosine_lr(2e-4, 7)                    # seven epochs into the schedule
+    fa.step_count = 5
+    fa.m.fill_(0.1)
+    fa.v.fill_(0.2)
+    sd = fa.state_dict()
+    assert sd["param_groups"][0]["initial_lr"] == 2e-4
+    start_epoch = 7
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    opt.load_state_dict(sd)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=1000, eta_min=1e-7, last_epoch=start_epoch - 1)
+    assert sched.base_lrs == [2e-4]
+    opt.step()
+    sched.step()
+    # the scheduler's constructor takes one step (to start_epoch) and the loop one more; torch's
+    # recursive form continues from the loaded lr, so allow for its drift against the closed form
+    assert abs(opt.param_groups[0]["lr"] - T.cosine_lr(2e-4, start_epoch + 1)) < 2e-8
+    # and a state written by the reference's optimizer (scheduler attached) loads back
+    fb = T.FlatAdam(flat, lr=1.0, shapes=[p.shape for p in m.parameters()])
+    fb.load_state_dict(opt.state_dict())
+    assert fb.initial_lr == 2e-4 and abs(fb.lr - T.cosine_lr(2e-4, start_epoch + 1)) < 2e-8
+
+
 def test_training_checkpoint_round_trip(tmp_path):
     CK = pkg("utils.checkpointing")
     g, d = _small_models()

@@ -39,6 +39,22 @@ def _worker(rank, world, port, q):
     sync = P.FlatGradAllReduce(world, bucket_mb=0.05)        # several buckets
     assert len(sync.buckets(fg.numel())) > 3
     sync(fg)
+    # the overlapped form: ranges handed over in backward order (last parameters first), merged
+    # into buckets, averaged — the same result as the one-shot form
+    fg2 = torch.cat([x.reshape(-1) for x in grads])
+    ov = P.OverlappedGradAllReduce(world, bucket_mb=0.05)
+    ov.begin(fg2)
+    cuts = list(range(0, fg2.numel(), 4001)) + [fg2.numel()]
+    for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        ov.ready(lo, hi)
+    ov.finish()
+    assert torch.equal(fg2, fg)
+    # replicas that start apart are made equal to rank 0's
+    t = torch.full((1000,), float(rank + 1))
+    u = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    P.broadcast_from_rank0([t, u])
+    assert torch.equal(t, torch.full((1000,), 1.0)) and torch.equal(u, torch.arange(5, dtype=torch.float32))
+    P.barrier()
     if rank == 0:
         out_full = O.generator_forward(lr, {k: p for (k, _), p in zip(g.named_parameters(), params)})
         gfull = torch.autograd.grad(O.l1_loss(out_full, hr), params)

@@ -35,6 +35,41 @@ def test_conv3x3_bias_lrelu(case, tdtype):
     assert rel_err(out, ref) < TOL[tdtype]
 
 
+# Dense-block shapes on images of at least 128 x 128 output pixels: the four-row-group tile shape
+# (32 x 16 output pixels per workgroup) that large patches run on (esrgan/generator.py:10-13 at
+# 128 x 128 LR patches), ragged sizes included.
+BIG_CASES = [
+    # B, cin, cout, H, W
+    (1, 64, 32, 128, 128),
+    (1, 96, 32, 128, 128),
+    (1, 128, 32, 144, 128),
+    (1, 160, 32, 128, 160),
+    (2, 64, 32, 130, 136),
+]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("epilogue", ["bias_lrelu", "mask"])
+@pytest.mark.parametrize("case", BIG_CASES)
+def test_conv3x3_large_image_dense_shapes(case, epilogue, tdtype):
+    B, cin, cout, H, W = case
+    E = pkg("engine")
+    assert E.conv_kernel_name(0 if tdtype == torch.bfloat16 else 1, 3, 1, H, W, cout, B).endswith(",1,1,4,5,3>")
+    x = O.hash_input(f"bx{case}", (B, cin, H, W))
+    w = O.hash_uniform(f"bw{case}", (cout, cin, 3, 3), (3.0 / (9 * cin)) ** 0.5)
+    if epilogue == "bias_lrelu":
+        b = O.hash_uniform(f"bb{case}", (cout,), 0.1)
+        ref = O.lrelu(O.conv3x3(x, w, b))
+        out = run_single_conv(x, w, b, tdtype=tdtype, act=0.2)
+    else:
+        # data-gradient form: no bias, output multiplied by the activation derivative of a saved tensor
+        mask = O.hash_input(f"bm{case}", (B, cout, H, W))
+        ref = O.conv3x3(x, w, None) * torch.where(mask > 0, 1.0, 0.2)
+        out = run_single_conv(x, w, None, tdtype=tdtype, mask=mask, mask_slope=0.2)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[tdtype]
+
+
 @pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
 def test_conv_residual_mask(tdtype):
     x = O.hash_input("xr", (2, 192, 10, 36))

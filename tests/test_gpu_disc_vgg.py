@@ -3,7 +3,7 @@ step (drop-in modules through the C ABI) against the reference-generated goldens
 import pytest
 import torch
 
-from helpers import O, TOL, fill_module_, golden, pkg, rel_err, rel_l2
+from helpers import O, TOL, fill_module_, full_grads_bad, golden, pkg, rel_err, rel_l2
 from test_gpu_generator import _grads_close
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,8 @@ def test_discriminator_fp32_matches_reference():
     assert rel_l2(xf.grad, torch.from_numpy(arr["d_gx_fake"])) < 2e-3
     bad = _grads_close(d, case["grads"], 2e-3)
     assert not bad, bad[:5]
+    bad = full_grads_bad(((n, p.grad) for n, p in d.named_parameters()), case["full_grads"], arr, 2e-3)
+    assert not bad, bad
     # third training forward (the G step's D(fake)) and an eval forward
     l3 = d(xf.detach())
     assert rel_err(l3, torch.from_numpy(arr["d_logits_third"])) < 1e-3
@@ -94,7 +96,7 @@ def test_vgg_features_match_oracle(tdtype):
     Lm = pkg("utils.loss")
     vgg_sd = O.make_state_dict(O.vgg19_state_dict_spec(), salt=7, gain=1.4)
     with pytest.warns(UserWarning):
-        m = Lm.VGGLoss(device="cuda")
+        m = Lm.VGGLoss(device="cuda", allow_synthetic=True)
     m.vgg.load_state_dict(vgg_sd)
     m.compute_dtype = tdtype
     x = O.hash_input("vgg.x", (1, 3, 32, 32))
@@ -130,7 +132,7 @@ def test_adversarial_step_fp32_matches_reference():
     g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=5).cuda()
     d = fill_module_(D.Discriminator(), salt=6).cuda()
     with pytest.warns(UserWarning):
-        vgg = Lm.VGGLoss(device="cuda")
+        vgg = Lm.VGGLoss(device="cuda", allow_synthetic=True)
     vgg.vgg.load_state_dict(O.make_state_dict(O.vgg19_state_dict_spec(), salt=7, gain=1.4))
     for m in (g, d, vgg):
         m.compute_dtype = torch.float32
@@ -147,6 +149,8 @@ def test_adversarial_step_fp32_matches_reference():
     assert abs(float(loss_disc.detach()) - case["loss_disc"]) < 1e-4
     bad = _grads_close(d, case["d_grads"], 3e-3)
     assert not bad, bad[:5]
+    bad = full_grads_bad(((n, p.grad) for n, p in d.named_parameters()), case["d_full_grads"], arr, 3e-3)
+    assert not bad, bad
     disc_fake_for_gen = d(fake)
     gen_adv = bce(disc_fake_for_gen, torch.ones_like(disc_fake_for_gen))
     gen_l1 = l1(fake, hr)
@@ -159,3 +163,5 @@ def test_adversarial_step_fp32_matches_reference():
         assert abs(float(v.detach()) - case[k]) / abs(case[k]) < 1e-3, k
     bad = _grads_close(g, case["g_grads"], 1e-2)
     assert not bad, bad[:5]
+    bad = full_grads_bad(((n, p.grad) for n, p in g.named_parameters()), case["g_full_grads"], arr, 1e-2)
+    assert not bad, bad

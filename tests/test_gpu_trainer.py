@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from helpers import O, fill_module_, golden, pkg, rel_err
+from helpers import O, fill_module_, full_grads_bad, golden, pkg, rel_err
 from test_gpu_generator import _grads_close
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +20,7 @@ def _models(num_blocks=2):
     g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=5).cuda()
     d = fill_module_(D.Discriminator(), salt=6).cuda()
     with pytest.warns(UserWarning):
-        vgg = Lm.VGGLoss(device="cuda")
+        vgg = Lm.VGGLoss(device="cuda", allow_synthetic=True)
     vgg.vgg.load_state_dict(O.make_state_dict(O.vgg19_state_dict_spec(), salt=7, gain=1.4))
     return g, d, vgg
 
@@ -28,7 +28,7 @@ def _models(num_blocks=2):
 def test_native_adversarial_step_matches_reference_golden():
     """lr = 0 keeps the discriminator weights unchanged between the D and the G step, which is
     how the golden 'adv_step' was produced (no optimizer in it)."""
-    man, _ = golden()
+    man, arr = golden()
     case = man["cases"]["adv_step"]
     T = pkg("train")
     g, d, vgg = _models()
@@ -44,10 +44,14 @@ def test_native_adversarial_step_matches_reference_golden():
         p.grad = tr.d_real.grads[n]
     bad = _grads_close(d, case["d_grads"], 3e-3)
     assert not bad, bad[:5]
+    bad = full_grads_bad(tr.d_real.grads.items(), case["d_full_grads"], arr, 3e-3)
+    assert not bad, bad
     for n, p in g.named_parameters():
         p.grad = tr.gplan.grads[n]
     bad = _grads_close(g, case["g_grads"], 1e-2)
     assert not bad, bad[:5]
+    bad = full_grads_bad(tr.gplan.grads.items(), case["g_full_grads"], arr, 1e-2)
+    assert not bad, bad
 
 
 def _dropin_step(g, d, vgg, opt_g, opt_d, lr, hr):
