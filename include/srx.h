@@ -266,6 +266,17 @@ typedef struct srx_sn_layer {
 } srx_sn_layer;
 int srx_sn_power_iter(const srx_sn_layer* layers /*DEVICE*/, int n, int do_power_iteration,
                       int max_rows, int max_cols, void* stream);
+/* srx_sn_power_iter for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the same computation and results, but the per-layer
+ * W v scratch rows live in a static device array inside the library instead of in the caller's
+ * `wv` buffers (srx_sn_layer.wv is ignored and may be NULL).  No counterpart in the reference.
+ * Limit: n * max_rows <= srx_sn_scratch_floats() (65536 floats = 256 KB per GPU, held until the
+ * process ends); larger problems are rejected with SRX_ERR_INVALID.  Calls no hipMalloc / hipFree
+ * or any allocating routine.  Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; serialise them or use srx_sn_power_iter. */
+int srx_sn_power_iter_noalloc(const srx_sn_layer* layers /*DEVICE*/, int n, int do_power_iteration,
+                              int max_rows, int max_cols, void* stream);
+int srx_sn_scratch_floats(void);
 /* dW_orig = dW_sn*inv_sigma - (<dW_sn, W_orig> * inv_sigma^2) u v^T, in place on
  * dw (fp32 [rows][cols]).  Autograd of spectral_norm.py:112-113. */
 typedef struct srx_sn_bwd_layer {

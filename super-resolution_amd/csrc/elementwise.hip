@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of libsrx: layout conversion, weight packing, pooling,
 // pixel (un)shuffle helpers, reductions, losses, spectral norm, Adam.
 // All are wave64, one 16/32-byte octet per lane per access, grid-strided.
+#include <mutex>
 #include "srx_common.h"
 
 namespace {
@@ -544,9 +545,11 @@ __device__ __forceinline__ float vec_inv_norm(const float* v, int n, float eps, 
   return 1.f / fmaxf(sqrtf(t), eps);
 }
 
-__global__ void sn_w_v_kernel(const srx_sn_layer* __restrict__ layers, int do_pi) {
+// wv_base != nullptr: layer l's W v rows live at wv_base + l * wv_stride instead of at layers[l].wv
+__global__ void sn_w_v_kernel(const srx_sn_layer* __restrict__ layers, int do_pi, float* wv_base, int wv_stride) {
   __shared__ float sh[4];
   const srx_sn_layer L = layers[blockIdx.y];
+  float* const wv = wv_base ? wv_base + (long)blockIdx.y * wv_stride : L.wv;
   if ((int)blockIdx.x * 4 >= L.rows) return;
   const float sc = do_pi ? vec_inv_norm(L.v, L.cols, 1e-12f, sh) : 1.f;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -555,24 +558,55 @@ __global__ void sn_w_v_kernel(const srx_sn_layer* __restrict__ layers, int do_pi
   float acc = 0.f;
   for (int c = lane; c < L.cols; c += 64) acc += L.w[(long)row * L.cols + c] * L.v[c];
   acc = wave_sum(acc);
-  if (lane == 0) L.wv[row] = acc * sc;
+  if (lane == 0) wv[row] = acc * sc;
 }
 
-__global__ void sn_finish_kernel(const srx_sn_layer* __restrict__ layers, int do_pi) {
+__global__ void sn_finish_kernel(const srx_sn_layer* __restrict__ layers, int do_pi, const float* wv_base,
+                                 int wv_stride) {
   __shared__ float sh[4];
   const srx_sn_layer L = layers[blockIdx.x];
+  const float* const wv = wv_base ? wv_base + (long)blockIdx.x * wv_stride : L.wv;
   if (do_pi) {
     const float sv = vec_inv_norm(L.v, L.cols, 1e-12f, sh);
     __syncthreads();
     for (int i = threadIdx.x; i < L.cols; i += blockDim.x) L.v[i] *= sv;
-    const float su = vec_inv_norm(L.wv, L.rows, 1e-12f, sh);
-    for (int i = threadIdx.x; i < L.rows; i += blockDim.x) L.u[i] = L.wv[i] * su;
+    const float su = vec_inv_norm(wv, L.rows, 1e-12f, sh);
+    for (int i = threadIdx.x; i < L.rows; i += blockDim.x) L.u[i] = wv[i] * su;
     __syncthreads();
   }
   float a = 0.f;
-  for (int i = threadIdx.x; i < L.rows; i += blockDim.x) a += L.u[i] * L.wv[i];
+  for (int i = threadIdx.x; i < L.rows; i += blockDim.x) a += L.u[i] * wv[i];
   float sigma = block_sum(a, sh);
   if (threadIdx.x == 0) L.inv_sigma[0] = 1.f / sigma;
+}
+
+// ---- static scratch of the entry point that allocates nothing ----
+// srx_sn_power_iter_noalloc keeps the W v rows of all layers here instead of in caller-provided
+// buffers.  One copy per GPU the library runs on, held until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: the device address it returns (one per
+// device) is what kernels and memory calls are given.
+constexpr int SN_SCRATCH_FLOATS = 64 * 1024;                     // 256 KB
+static __device__ __align__(256) float sn_scratch[SN_SCRATCH_FLOATS];
+
+constexpr int SN_MAX_DEVICES = 64;
+static float* g_sn_scratch_ptr[SN_MAX_DEVICES];
+static std::mutex g_sn_scratch_mutex;
+
+// Device address of sn_scratch on the CURRENT device, resolved once per device.
+static int sn_scratch_ptr(float** out) {
+  int dev = -1;
+  SRX_CHECK_HIP(hipGetDevice(&dev));
+  SRX_CHECK_ARG(dev >= 0 && dev < SN_MAX_DEVICES, "device ordinal %d outside the library's table of %d", dev,
+                SN_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_sn_scratch_mutex);
+  if (g_sn_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    SRX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(sn_scratch)));
+    SRX_CHECK_ARG(p != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
+    g_sn_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_sn_scratch_ptr[dev];
+  return SRX_OK;
 }
 
 __global__ void sn_bwd_dot_kernel(const srx_sn_bwd_layer* __restrict__ layers) {
@@ -800,16 +834,39 @@ int srx_bce_logits(int dtype, const void* logits, int n, float target, float wei
   return srx_check_launch("bce_logits");
 }
 
-int srx_sn_power_iter(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols, void* stream) {
-  SRX_CHECK_ARG(layers && n > 0 && max_rows > 0 && max_cols > 0, "srx_sn_power_iter: bad argument");
+static int sn_power_iter_launch(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols,
+                                float* wv_base, int wv_stride, void* stream) {
   if (do_pi) {
     hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + SN_COLS - 1) / SN_COLS, n), dim3(TPB), 0, STREAM, layers);
     if (int rc = srx_check_launch("sn_wt_u")) return rc;
   }
-  hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_rows + 3) / 4, n), dim3(TPB), 0, STREAM, layers, do_pi);
+  hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_rows + 3) / 4, n), dim3(TPB), 0, STREAM, layers, do_pi, wv_base,
+                     wv_stride);
   if (int rc = srx_check_launch("sn_w_v")) return rc;
-  hipLaunchKernelGGL(sn_finish_kernel, dim3(n), dim3(TPB), 0, STREAM, layers, do_pi);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(n), dim3(TPB), 0, STREAM, layers, do_pi, (const float*)wv_base,
+                     wv_stride);
   return srx_check_launch("sn_finish");
+}
+
+int srx_sn_power_iter(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols, void* stream) {
+  SRX_CHECK_ARG(layers && n > 0 && max_rows > 0 && max_cols > 0, "srx_sn_power_iter: bad argument");
+  return sn_power_iter_launch(layers, n, do_pi, max_rows, max_cols, nullptr, 0, stream);
+}
+
+int srx_sn_scratch_floats(void) { return SN_SCRATCH_FLOATS; }
+
+int srx_sn_power_iter_noalloc(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols,
+                              void* stream) {
+  SRX_CHECK_ARG(layers && n > 0 && max_rows > 0 && max_cols > 0, "srx_sn_power_iter_noalloc: bad argument");
+  SRX_CHECK_ARG((long)n * max_rows <= (long)SN_SCRATCH_FLOATS,
+                "srx_sn_power_iter_noalloc: n * max_rows = %ld floats of scratch needed, the library's static "
+                "scratch holds %d; use srx_sn_power_iter with caller-provided wv buffers",
+                (long)n * max_rows, SN_SCRATCH_FLOATS);
+  float* ptr = nullptr;
+  if (int rc = sn_scratch_ptr(&ptr)) return rc;
+  // every row the finishing kernel reads is written by the kernel before it in this same call:
+  // nothing of an earlier call's contents is read, so the array needs no clearing
+  return sn_power_iter_launch(layers, n, do_pi, max_rows, max_cols, ptr, max_rows, stream);
 }
 
 int srx_sn_backward(const srx_sn_bwd_layer* layers, int n, int max_elems, void* stream) {
