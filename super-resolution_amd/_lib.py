@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrx.so")
+# SRX_LIB_PATH: another build of the library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("SRX_LIB_PATH") or os.path.join(_HERE, "libsrx.so")
 
 BF16, F32 = 0, 1
 

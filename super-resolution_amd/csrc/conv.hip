@@ -107,6 +107,9 @@ void conv_kernel(const ConvParams p) {
   constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
   constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
   static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
+  // consecutive row groups of a wave are consecutive image rows: activation fragments are shared
+  // between tap rows (see the K loop)
+  constexpr bool XROWS = (STRIDE == 1 && LTW == 5 && KS == 3 && RW > 1);
 
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
   extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];   // NSTG ring stages
@@ -263,29 +266,67 @@ void conv_kernel(const ConvParams p) {
     const frag_t* sw = reinterpret_cast<const frag_t*>(smem + stage * STAGE + XPP);
     // Fragment reads run one tap ROW (KS taps) ahead of the MFMAs that consume them: with one
     // wave per SIMD nothing else hides the LDS latency.
-    frag_t wf[2][KS][NB], xf[2][KS][RW];
-    auto read_row = [&](int dy, int buf) {
+    if constexpr (XROWS) {
+      // A row group is one image row here (32-pixel-wide tiles, stride 1), so the input row that
+      // tap row dy feeds to row group rg is row rg + dy of the wave's part of the halo tile: the
+      // fragment of (dy, rg) is the fragment of (dy - 1, rg + 1).  Each of the RW + KS - 1 input
+      // rows is read once per chunk into a register window and used by every tap row that
+      // touches it: (RW + 2) * 3 activation reads per chunk instead of RW * 9.
+      frag_t wf[2][KS][NB], xw[RW + KS - 1][KS];
+      auto read_w = [&](int dy, int buf) {
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx) {
-        const int tap = dy * KS + dx;
+        for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) wf[buf][dx][n] = sw[(((bg * NB + n) * TAPS + tap) * 2 + hh) * 32 + pl];
+          for (int n = 0; n < NB; ++n)
+            wf[buf][dx][n] = sw[(((bg * NB + n) * TAPS + dy * KS + dx) * 2 + hh) * 32 + pl];
+      };
+      auto read_xrow = [&](int r) {
 #pragma unroll
-        for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
+        for (int dx = 0; dx < KS; ++dx) xw[r][dx] = sx[xslot[0] + r * IW + dx];
+      };
+      read_w(0, 0);
+#pragma unroll
+      for (int r = 0; r < RW; ++r) read_xrow(r);
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        if (dy + 1 < KS) {
+          read_w(dy + 1, (dy + 1) & 1);
+          read_xrow(dy + RW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+          for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xw[rg + dy][dx], acc[rg][n]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    read_row(0, 0);
+    } else {
+      frag_t wf[2][KS][NB], xf[2][KS][RW];
+      auto read_row = [&](int dy, int buf) {
 #pragma unroll
-    for (int dy = 0; dy < KS; ++dy) {
-      if (dy + 1 < KS) read_row(dy + 1, (dy + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int dx = 0; dx < KS; ++dx) {
+          const int tap = dy * KS + dx;
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx)
+          for (int n = 0; n < NB; ++n) wf[buf][dx][n] = sw[(((bg * NB + n) * TAPS + tap) * 2 + hh) * 32 + pl];
 #pragma unroll
-        for (int rg = 0; rg < RW; ++rg)
+          for (int rg = 0; rg < RW; ++rg) xf[buf][dx][rg] = sx[xslot[rg] + dy * IW + dx];
+        }
+      };
+      read_row(0, 0);
 #pragma unroll
-          for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int dy = 0; dy < KS; ++dy) {
+        if (dy + 1 < KS) read_row(dy + 1, (dy + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+          for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) mma(wf[dy & 1][dx][n], xf[dy & 1][dx][rg], acc[rg][n]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     stage = stage == NSTG - 1 ? 0 : stage + 1;
   }
@@ -347,15 +388,15 @@ void conv_kernel(const ConvParams p) {
 #pragma unroll
     for (int rg = 0; rg < RW; ++rg) {
       if (eoff[rg] < 0) continue;
-      T* yrow;
+      long yrow;                       // element offset inside the image's output
       long ostep;                      // element step between consecutive stored octets (j, then n)
       if (p.ps) {                      // PixelShuffle(2): sub-pixel (hh, j) of output channel block nb
         const int g = pg * RW + rg;
         const int oy = oy0 + g * RPG + (pl >> LTW), ox = ox0 + (pl & (TW - 1));
-        yrow = yb + (long)nbw0 * 4 * plane_out + ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox) * 8;
+        yrow = (long)nbw0 * 4 * plane_out + ((long)(2 * oy + hh) * (2 * p.OW) + 2 * ox) * 8;
         ostep = 8;
       } else {
-        yrow = yb + (long)(nbw0 * 4 + hh) * plane_out + eoff[rg];
+        yrow = (long)(nbw0 * 4 + hh) * plane_out + eoff[rg];
         ostep = 2 * plane_out;
       }
 #pragma unroll
@@ -365,7 +406,7 @@ void conv_kernel(const ConvParams p) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = acc[rg][n][j * 8 + e];
-          store_oct(yrow + (p.ps ? (long)n * 4 * plane_out + j * ostep : (long)(n * 2 + j) * ostep), v);
+          store_oct(yb + yrow + (p.ps ? (long)n * 4 * plane_out + j * ostep : (long)(n * 2 + j) * ostep), v);
         }
     }
     return;

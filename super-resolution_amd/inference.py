@@ -60,7 +60,7 @@ class SuperResolutionInference:
 
     def __init__(self, model_name: str = "esrgan", checkpoint_path=None, half_precision: bool = False,
                  device: Optional[str] = None, *, model=None, num_features: int = 64, num_blocks: int = 23,
-                 tile_batch: int = 8, window: str = "hann"):
+                 tile_batch: int = 12, window: str = "hann"):
         if model_name != "esrgan":
             raise ValueError(f"Unknown model: '{model_name}'. Choose from ['esrgan']")
         device = device or "cuda"
@@ -123,12 +123,23 @@ class SuperResolutionInference:
             return out.clamp_(0, 1) if clamp else out
         if tile_overlap >= tile_size:
             raise ValueError("tile_overlap must be smaller than tile_size")
-        return torch.stack([self._infer_tiled(lr_tensor[i], tile_size, tile_overlap, clamp) for i in range(b)])
+        return self._infer_tiled_batch(lr_tensor, tile_size, tile_overlap, clamp)
 
     def _infer_tiled(self, img: torch.Tensor, tile: int, overlap: int, clamp: bool,
                      want_u8: bool = False) -> torch.Tensor:
         """One [c,h,w] image through the tile grid of inference.py:189-230."""
-        c, h, w = img.shape
+        return self._infer_tiled_batch(img.unsqueeze(0), tile, overlap, clamp, want_u8)[0]
+
+    def _infer_tiled_batch(self, imgs: torch.Tensor, tile: int, overlap: int, clamp: bool,
+                           want_u8: bool = False) -> torch.Tensor:
+        """[b,c,h,w] images through the tile grid of inference.py:189-230.  The grid is the
+        reference's (one tile every ``stride`` pixels of the reflect-padded image, clipped past
+        the padded edge).  A tile that starts at or beyond the image's own last row / column
+        covers padding only, which the final crop (inference.py:230) discards: it is not
+        computed.  The remaining tiles of ALL images go through the generator in equally sized
+        batches per tile shape, and the last convolution of each batch writes straight into the
+        tile store the blend kernel reads."""
+        nimg, c, h, w = imgs.shape
         stride = tile - overlap
         pad_h = max(0, (stride - (h - tile) % stride) % stride)               # inference.py:195-196
         pad_w = max(0, (stride - (w - tile) % stride) % stride)
@@ -137,53 +148,81 @@ class SuperResolutionInference:
         ph, pw = h + pad_h, w + pad_w
         ys, xs = list(range(0, ph, stride)), list(range(0, pw, stride))
         ny, nx = len(ys), len(xs)
-        tiles = (L.Tile * (ny * nx))()
-        by_shape: Dict[Tuple[int, int], List[int]] = {}
+        ntile = ny * nx
+        # per-image tile tables (the blend kernel's [ny][nx] grid), all in one host array
+        tables = (L.Tile * (nimg * ntile))()
+        by_shape: Dict[Tuple[int, int], List[Tuple[int, int]]] = {}
+        for i in range(nimg):
+            for ky, y in enumerate(ys):
+                for kx, x in enumerate(xs):
+                    t = tables[i * ntile + ky * nx + kx]
+                    t.y0, t.x0 = y, x
+                    if y < h and x < w:
+                        t.th, t.tw = min(y + tile, ph) - y, min(x + tile, pw) - x
+                        by_shape.setdefault((t.th, t.tw), []).append((i, ky * nx + kx))
+                    else:
+                        t.th = t.tw = 0          # covers cropped padding only: never read by the blend
+        # batches: per shape, as few as the batch limit allows, equally sized; store offsets in
+        # batch order so that a batch's outputs are one contiguous block
+        batches: List[Tuple[int, int, List[Tuple[int, int]]]] = []
         off = 0
-        for ky, y in enumerate(ys):
-            for kx, x in enumerate(xs):
-                t = tiles[ky * nx + kx]
-                t.y0, t.x0 = y, x
-                t.th, t.tw = min(y + tile, ph) - y, min(x + tile, pw) - x
-                t.offset = off
-                off += t.th * SCALE * t.tw * SCALE * 8
-                by_shape.setdefault((t.th, t.tw), []).append(ky * nx + kx)
+        for (th, tw), jobs in by_shape.items():
+            nb = -(-len(jobs) // self.tile_batch)
+            per = -(-len(jobs) // nb)
+            n_el = th * SCALE * tw * SCALE * 8
+            for s_ in range(0, len(jobs), per):
+                part = jobs[s_:s_ + per]
+                for (i, k) in part:
+                    tables[i * ntile + k].offset = off
+                    off += n_el
+                batches.append((th, tw, part))
         store = torch.empty(off, dtype=self.tdtype, device=self.device)
-        grid_dev = torch.frombuffer(bytearray(C.string_at(C.addressof(tiles), C.sizeof(tiles))),
-                                    dtype=torch.uint8).to(self.device)
+        # gather tables: the jobs of each batch in order (one gather launch per run of one image)
+        order = [(i, k) for _, _, part in batches for (i, k) in part]
+        gtab = (L.Tile * len(order))(*[tables[i * ntile + k] for (i, k) in order])
+        raw = C.string_at(C.addressof(tables), C.sizeof(tables)) + C.string_at(C.addressof(gtab), C.sizeof(gtab))
+        tab_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        gtab_ptr = tab_dev.data_ptr() + C.sizeof(tables)
+        tsz = C.sizeof(L.Tile)
         dt = engine.dtype_id(self.tdtype)
         esize = store.element_size()
-        keep = [grid_dev]
-        for (th, tw), idxs in by_shape.items():
-            for s in range(0, len(idxs), self.tile_batch):
-                part = idxs[s:s + self.tile_batch]
-                plan = self._plan(len(part), th, tw)
-                sub = (L.Tile * len(part))(*[tiles[i] for i in part])
-                sub_dev = torch.frombuffer(bytearray(C.string_at(C.addressof(sub), C.sizeof(sub))),
-                                           dtype=torch.uint8).to(self.device)
-                keep.append(sub_dev)
-                plan.run_packing()
-                L.check(self.lib.srx_tile_gather(dt, img.data_ptr(), c, h, w, sub_dev.data_ptr(), len(part),
-                                                 th, tw, plan.X0.ptr(), plan.X0.img_stride, self._sp()),
-                        "srx_tile_gather")
+        pos = 0
+        for th, tw, part in batches:
+            plan = self._plan(len(part), th, tw)
+            plan.run_packing()
+            j = 0
+            while j < len(part):                     # runs of one image: one gather launch each
+                j1 = j
+                while j1 + 1 < len(part) and part[j1 + 1][0] == part[j][0]:
+                    j1 += 1
+                L.check(self.lib.srx_tile_gather(dt, imgs[part[j][0]].data_ptr(), c, h, w, gtab_ptr + (pos + j) * tsz,
+                                                 j1 - j + 1, th, tw,
+                                                 plan.X0.ptr() + j * plan.X0.img_stride * esize,
+                                                 plan.X0.img_stride, self._sp()), "srx_tile_gather")
+                j = j1 + 1
+            # the plan's last convolution (conv_last) writes this batch's block of the store
+            last = plan.fwd_ops[len(plan.fwd_ops) - 1].u.conv
+            own_y = last.y
+            last.y = store.data_ptr() + tables[part[0][0] * ntile + part[0][1]].offset * esize
+            try:
                 plan.run(plan.fwd_ops)
-                n_el = th * SCALE * tw * SCALE * 8
-                for j, i in enumerate(part):       # tiles of a batch may be non-adjacent in the store
-                    o = tiles[i].offset
-                    store[o:o + n_el].copy_(plan.Y.t[j * n_el:(j + 1) * n_el])
+            finally:
+                last.y = own_y
+            pos += len(part)
         win = self._windows.get(tile)
         if win is None:
             win = blend_window(tile * SCALE, self.window_kind).to(self.device)
             self._windows[tile] = win
         OH, OW = h * SCALE, w * SCALE
-        out = torch.empty((c, OH, OW), dtype=torch.float32, device=self.device)
-        out_u8 = torch.empty((c, OH, OW), dtype=torch.uint8, device=self.device) if want_u8 else None
-        L.check(self.lib.srx_tile_blend(dt, store.data_ptr(), grid_dev.data_ptr(), ny, nx, stride, tile, SCALE,
-                                        win.data_ptr(), out.data_ptr(),
-                                        out_u8.data_ptr() if out_u8 is not None else None, c, OH, OW,
-                                        1 if clamp else 0, self._sp()), "srx_tile_blend")
-        self._keep = keep                           # descriptors stay alive until the stream is done
-        return out_u8 if want_u8 else out
+        out = torch.empty((nimg, c, OH, OW), dtype=torch.uint8 if want_u8 else torch.float32, device=self.device)
+        for i in range(nimg):
+            L.check(self.lib.srx_tile_blend(dt, store.data_ptr(), tab_dev.data_ptr() + i * ntile * tsz, ny, nx, stride,
+                                            tile, SCALE, win.data_ptr(),
+                                            None if want_u8 else out[i].data_ptr(),
+                                            out[i].data_ptr() if want_u8 else None, c, OH, OW,
+                                            1 if clamp else 0, self._sp()), "srx_tile_blend")
+        self._keep = (tab_dev, store)               # stay alive until the stream is done with them
+        return out
 
     @torch.no_grad()
     def run(self, lr_image, tile_size: int = 0, tile_overlap: int = 32):
