@@ -247,7 +247,6 @@ def main():
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--wgrad-overlap", type=int, default=1, help="weight gradients on a side stream (0/1)")
     ap.add_argument("--skip-wgrad", action="store_true", help="diagnostic: drop weight-gradient launches (INVALID as a result)")
-    ap.add_argument("--graphs", type=int, default=0, help="replay recorded op lists as HIP graphs (0/1)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     ap.add_argument("--pair-wgrad-tasks", type=int, default=0,
@@ -305,7 +304,6 @@ def main():
     sync = D.OverlappedGradAllReduce(world, bucket_mb=8.0, single_rank_too=True) if exchange else None
     if args.skip_wgrad:
         E.Plan.wgrad = lambda self, ops, *a, **k: None
-    E.Plan.use_graphs = bool(args.graphs)
     E.Plan.pair_wgrad_tasks = bool(args.pair_wgrad_tasks)
     T.GeneratorWarmupTrainer.step_in_backward = bool(args.adam_in_backward)
     T.AdversarialTrainer.step_in_backward = bool(args.adam_in_backward)

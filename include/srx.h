@@ -37,7 +37,7 @@ int srx_version(void);
 const char* srx_last_error(void);
 /* sizeof() of the ABI structs, for binding self-checks: 0 srx_conv_desc, 1 srx_wgrad_task,
  * 2 srx_wgrad_desc, 3 srx_pack_seg, 4 srx_pack_layer, 5 srx_unpack_item, 6 srx_sn_layer,
- * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop, 12 srx_conv_pair_desc; -1 for an unknown id. */
+ * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop; -1 for an unknown id. */
 int srx_sizeof(int which);
 
 /* ------------------------------------------------------------------ layout */
@@ -116,32 +116,6 @@ typedef struct srx_conv_desc {
  * esrgan/discriminator.py:12-13,30-32; VGG conv+ReLU, utils/loss.py:15), and,
  * with transposed/flipped packed weights, the data gradient of the same. */
 int srx_conv2d(const srx_conv_desc* d, void* stream);
-
-/* Two consecutive 3x3 / stride-1 / pad-1 convolutions of a dense block in one launch (bf16):
- * A: X (cin_a channels, a multiple of 16) -> 32 channels, B: (X and A's output) -> 32
- * channels — convolutions k and k+1 of ResidualDenseBlock.forward (esrgan/generator.py:
- * 18-21), and likewise two consecutive steps of the block's data-gradient chain.  Each
- * convolution's epilogue is v = acc + bias; v *= (mask > 0 ? 1 : mask_slope) if its mask is
- * given; v = max(v, act_slope*v) (act_slope in [0,1]; 1: identity).  wb is B's packed weight
- * (srx_pack_weights, cin = cin_a + 32) with A's 32 output channels as its LAST input
- * channels, or as its FIRST when a_out_first is set.  ya / yb may be other planes of the
- * buffer x points into.  Results are those of two srx_conv2d calls. */
-typedef struct srx_conv_pair_desc {
-  int32_t dtype;        /* SRX_BF16 */
-  int32_t B, H, W;
-  int32_t cin_a;
-  int32_t a_out_first;
-  const void* x;  int64_t x_img_stride;
-  void* ya;       int64_t ya_img_stride;
-  void* yb;       int64_t yb_img_stride;
-  const void* wa; const void* wb;
-  const float* bias_a; const float* bias_b;       /* packed biases or NULL */
-  const void* mask_a; int64_t mask_a_img_stride;
-  const void* mask_b; int64_t mask_b_img_stride;
-  float mask_slope;
-  float act_slope;
-} srx_conv_pair_desc;
-int srx_conv2d_pair(const srx_conv_pair_desc* d, void* stream);
 
 /* --------------------------------------------------------- weight gradients */
 /* One 64x64 (cin x cout) block task of a weight-gradient launch: four 32x32
@@ -350,7 +324,6 @@ int srx_crop_augment(const srx_crop* crops /*DEVICE*/, int B, int size, float* o
 #define SRX_OP_GAP_FWD 10
 #define SRX_OP_GAP_BWD 11
 #define SRX_OP_ACT_BWD 12
-#define SRX_OP_CONV_PAIR 13
 
 typedef struct srx_generic_args {   /* for the bandwidth-bound helpers */
   int32_t dtype, B, C, H, W, noct;
@@ -369,23 +342,12 @@ typedef struct srx_op {
     srx_conv_desc conv;
     srx_wgrad_desc wgrad;
     srx_generic_args g;
-    srx_conv_pair_desc pair;
   } u;
 } srx_op;
 
 /* Launch a recorded sequence of ops back to back on one stream with a single
  * crossing of the language boundary (a whole generator forward or backward). */
 int srx_run_ops(const srx_op* ops, int n, void* stream);
-/* The same sequence captured once as a HIP graph and replayed with one call: a host launch
- * costs ~3.5 us, so chains of short kernels (small patches, tiled inference) are otherwise
- * bound by the host.  Every op of the list must have run once through srx_run_ops before
- * (kernels set their attributes on first use); descriptors and the memory they point at must
- * stay as they were at capture.  The graph objects are the only thing libsrx ever allocates;
- * destroy them with srx_graph_destroy. */
-int srx_graph_capture(const srx_op* ops, int n, void** graph_exec);
-int srx_graph_launch(void* graph_exec, void* stream);
-int srx_graph_destroy(void* graph_exec);
-
 /* A non-blocking stream of the given HIP priority (1 low, 0 normal, -1 high) on the current
  * device, for the weight-gradient launches that run beside the data-gradient chain.  The runtime
  * keeps one pool of hardware queues per priority (four queues each by default): a side stream of

@@ -32,3 +32,5 @@ bench(64, 128, 128, 160, 32, reps=50)
 bench(64, 128, 128, 192, 64, reps=50)
 bench(16, 256, 256, 64, 64, reps=50)
 bench(16, 64, 64, 64, 32, torch.float32)
+for cin in (64, 128, 192, 256):
+    bench(16, 64, 64, cin, 64)

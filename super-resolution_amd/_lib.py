@@ -22,7 +22,6 @@ BF16, F32 = 0, 1
 OP_CONV, OP_WGRAD, OP_PIXEL_UNSHUFFLE, OP_CHANNEL_SUM, OP_ZERO_STUFF = 1, 2, 3, 4, 5
 OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_MEMSET, OP_AXPBY, OP_GAP_FWD, OP_GAP_BWD = 6, 7, 8, 9, 10, 11
 OP_ACT_BWD = 12
-OP_CONV_PAIR = 13
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -92,16 +91,8 @@ class Crop(C.Structure):
     _fields_ = [("img", vp), ("H", i32), ("W", i32), ("y0", i32), ("x0", i32), ("flags", i32), ("pad_", i32)]
 
 
-class ConvPairDesc(C.Structure):
-    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("cin_a", i32), ("a_out_first", i32),
-                ("x", vp), ("x_img_stride", i64), ("ya", vp), ("ya_img_stride", i64),
-                ("yb", vp), ("yb_img_stride", i64), ("wa", vp), ("wb", vp), ("bias_a", vp), ("bias_b", vp),
-                ("mask_a", vp), ("mask_a_img_stride", i64), ("mask_b", vp), ("mask_b_img_stride", i64),
-                ("mask_slope", f32), ("act_slope", f32)]
-
-
 class _OpU(C.Union):
-    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs), ("pair", ConvPairDesc)]
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs)]
 
 
 class Op(C.Structure):
@@ -117,7 +108,6 @@ _SIGS = {
     "srx_pack_weights": (C.c_int, [C.c_int, vp, vp, C.c_int, i64, vp]),
     "srx_pack_weights_scaled": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, i64, vp]),
     "srx_conv2d": (C.c_int, [C.POINTER(ConvDesc), vp]),
-    "srx_conv2d_pair": (C.c_int, [C.POINTER(ConvPairDesc), vp]),
     "srx_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
     "srx_unpack_wgrad": (C.c_int, [vp, C.c_int, i64, vp]),
     "srx_channel_sum": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
@@ -142,9 +132,6 @@ _SIGS = {
     "srx_sn_backward": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "srx_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
     "srx_run_ops": (C.c_int, [vp, C.c_int, vp]),
-    "srx_graph_capture": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
-    "srx_graph_launch": (C.c_int, [vp, vp]),
-    "srx_graph_destroy": (C.c_int, [vp]),
     "srx_stream_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "srx_stream_destroy": (C.c_int, [vp]),
     "srx_tile_gather": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
@@ -172,7 +159,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         structs = (ConvDesc, WgradTask, WgradDesc, PackSeg, PackLayer, UnpackItem, SnLayer,
-                   SnBwdLayer, GenericArgs, Op, Tile, Crop, ConvPairDesc)
+                   SnBwdLayer, GenericArgs, Op, Tile, Crop)
         for i, st in enumerate(structs):
             if l.srx_sizeof(i) != C.sizeof(st):
                 raise RuntimeError(f"libsrx ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in "

@@ -34,7 +34,6 @@ int srx_sizeof(int which) {
     case 9: return (int)sizeof(srx_op);
     case 10: return (int)sizeof(srx_tile);
     case 11: return (int)sizeof(srx_crop);
-    case 12: return (int)sizeof(srx_conv_pair_desc);
     default: return -1;
   }
 }
@@ -48,7 +47,6 @@ int srx_run_ops(const srx_op* ops, int n, void* stream) {
     int rc = SRX_OK;
     switch (op.kind) {
       case SRX_OP_CONV: rc = srx_conv2d(&op.u.conv, stream); break;
-      case SRX_OP_CONV_PAIR: rc = srx_conv2d_pair(&op.u.pair, stream); break;
       case SRX_OP_WGRAD: rc = srx_conv2d_wgrad(&op.u.wgrad, stream); break;
       case SRX_OP_PIXEL_UNSHUFFLE:
         rc = srx_pixel_unshuffle2(g.dtype, g.a, g.a_img_stride, g.c, g.c_img_stride, g.B, g.C, g.H, g.W, stream);
@@ -91,57 +89,6 @@ int srx_run_ops(const srx_op* ops, int n, void* stream) {
       return rc;
     }
   }
-  return SRX_OK;
-}
-
-// ---- recorded op lists as HIP graphs ------------------------------------------------------
-// A host launch costs ~3.5 us; a chain of 5 us kernels (small patches, tiled inference) is then
-// bound by the host, not the GPU.  An op list whose descriptors do not change can be captured
-// once and replayed with one call.
-int srx_graph_capture(const srx_op* ops, int n, void** graph_exec) {
-  SRX_CHECK_ARG(ops != nullptr && n > 0 && graph_exec != nullptr, "srx_graph_capture: bad argument");
-  *graph_exec = nullptr;
-  // capture on a stream of our own: the caller's may be the legacy default stream, which cannot
-  // be captured; the resulting graph is not tied to the stream it was recorded on
-  hipStream_t cs = nullptr;
-  SRX_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) {
-    (void)hipStreamDestroy(cs);
-    srx_set_error("srx_graph_capture: hipStreamBeginCapture failed: %s", hipGetErrorString(e));
-    return SRX_ERR_HIP;
-  }
-  const int rc = srx_run_ops(ops, n, cs);
-  hipGraph_t g = nullptr;
-  e = hipStreamEndCapture(cs, &g);
-  (void)hipStreamDestroy(cs);
-  if (rc != SRX_OK) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
-  }
-  if (e != hipSuccess || g == nullptr) {
-    srx_set_error("srx_graph_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    return SRX_ERR_HIP;
-  }
-  hipGraphExec_t ex = nullptr;
-  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (e != hipSuccess) {
-    srx_set_error("srx_graph_capture: hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    return SRX_ERR_HIP;
-  }
-  *graph_exec = ex;
-  return SRX_OK;
-}
-
-int srx_graph_launch(void* graph_exec, void* stream) {
-  SRX_CHECK_ARG(graph_exec != nullptr, "srx_graph_launch: null graph");
-  SRX_CHECK_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), reinterpret_cast<hipStream_t>(stream)));
-  return SRX_OK;
-}
-
-int srx_graph_destroy(void* graph_exec) {
-  if (graph_exec) SRX_CHECK_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
   return SRX_OK;
 }
 

@@ -245,39 +245,6 @@ class Plan:
             ops.meta.append((conv_kernel_name(self.dt, ksize, stride, OH, OW, cout, B),
                              2.0 * B * OH * OW * ksize * ksize * cin * cout))
 
-    # Consecutive 32-channel convolutions of a dense block in one launch (srx_conv2d_pair, bf16).
-    # Off by default: measured on MI355X the fused launch takes as long as the two it replaces at
-    # 64x64 patches (14.6 vs 14.6 us at 64 input channels, 19.6 vs 19.0 us at 128: the launch it
-    # saves is paid back by the 25 % halo recompute and the extra barriers) and is 1.4x slower at
-    # 128x128 patches.
-    use_conv_pairs = False
-
-    def pair_ok(self, W: int, cin_a: int, cout_a: int, cout_b: int, force: bool = False) -> bool:
-        return ((self.use_conv_pairs or force) and self.dt == L.BF16 and W >= 24 and cin_a % 16 == 0
-                and cout_a == 32 and cout_b == 32)
-
-    def conv_pair(self, ops: list, x: View, ya: View, yb: View, wa: int, wb: int, bias_a: int, bias_b: int,
-                  B: int, H: int, W: int, cin_a: int, *, act: float = 1.0, mask_a: Optional[View] = None,
-                  mask_b: Optional[View] = None, mask_slope: float = 0.0, a_out_first: bool = False):
-        """srx_conv2d_pair: A: x (cin_a) -> 32 channels at ya; B: (x, A's output) -> 32 at yb."""
-        op = L.Op()
-        op.kind = L.OP_CONV_PAIR
-        d = op.u.pair
-        d.dtype, d.B, d.H, d.W, d.cin_a, d.a_out_first = self.dt, B, H, W, cin_a, 1 if a_out_first else 0
-        d.x, d.x_img_stride = x[0].ptr(x[1]), x[0].img_stride
-        d.ya, d.ya_img_stride = ya[0].ptr(ya[1]), ya[0].img_stride
-        d.yb, d.yb_img_stride = yb[0].ptr(yb[1]), yb[0].img_stride
-        d.wa, d.wb = wa, wb
-        d.bias_a, d.bias_b = bias_a or None, bias_b or None
-        if mask_a is not None:
-            d.mask_a, d.mask_a_img_stride = mask_a[0].ptr(mask_a[1]), mask_a[0].img_stride
-        if mask_b is not None:
-            d.mask_b, d.mask_b_img_stride = mask_b[0].ptr(mask_b[1]), mask_b[0].img_stride
-        d.mask_slope, d.act_slope = mask_slope, act
-        ops.append(op)
-        if isinstance(ops, OpList):
-            ops.meta.append(("conv_pair_kernel<bf16>", 2.0 * B * H * W * 9 * (cin_a * 32 + (cin_a + 32) * 32)))
-
     def generic(self, ops: list, kind: int, *, a: Optional[View] = None, b: Optional[View] = None,
                 c: Optional[View] = None, c_ptr: int = 0, mask: Optional[View] = None,
                 B=0, C_=0, H=0, W=0, noct=0, f0=0.0, f1=0.0, n=0):
@@ -467,40 +434,12 @@ class Plan:
     def freeze(ops: list):
         return (L.Op * len(ops))(*ops) if ops else None
 
-    # Replay recorded op lists as HIP graphs from their second run on.  Off by default: measured on
-    # MI355X / ROCm 7.2 a replay keeps the same ~2-4 us between short kernels as plain launches
-    # (config 3: 12.8 vs 12.95 ms/step), so it buys nothing here.
-    use_graphs = False
-    _GRAPH_MIN_OPS = 8
-
     def run(self, frozen, stream: Optional[torch.cuda.Stream] = None) -> None:
         if frozen is None:
             return
         sp = stream.cuda_stream if stream is not None else stream_ptr(self.device)
         n = len(frozen)
-        if self.use_graphs and n >= self._GRAPH_MIN_OPS:
-            graphs = self.__dict__.setdefault("_graphs", {})
-            key = C.addressof(frozen)
-            g = graphs.get(key)
-            if g is None:
-                # first run: plain launches (kernels set their attributes on first use)
-                graphs[key] = 0
-            elif g == 0:
-                ex = C.c_void_p()
-                L.check(self.lib.srx_graph_capture(key, n, C.byref(ex)), "srx_graph_capture")
-                graphs[key] = g = (ex, frozen)          # keeps the descriptor array alive
-            if g:
-                L.check(self.lib.srx_graph_launch(g[0], sp), "srx_graph_launch")
-                return
         L.check(self.lib.srx_run_ops(C.addressof(frozen), n, sp), "srx_run_ops")
-
-    def __del__(self):
-        try:
-            for g in self.__dict__.get("_graphs", {}).values():
-                if g:
-                    self.lib.srx_graph_destroy(g[0])
-        except Exception:
-            pass
 
     # ------------------------------------------------- two-stream op lists
     # Weight-gradient launches depend only on tensors the data-gradient chain has already
@@ -655,19 +594,9 @@ class _GenBase(Plan):
         enclosing RRDB's ``out*0.2 + x`` (:37) in the same epilogue."""
         nf8, gc8 = nf // 8, gc // 8
         packed = {k: self.fwd_layer(P, pre + f"conv{k}") for k in range(1, 5)}
-        k = 1
-        while k < 5:
-            cin = nf + (k - 1) * gc
-            if k < 4 and self.pair_ok(w, cin, gc, gc):
-                # convolutions k and k+1 in one launch: k+1 reads what k read plus k's output
-                self.conv_pair(ops, (cur, 0), (cur, nf8 + (k - 1) * gc8), (cur, nf8 + k * gc8),
-                               packed[k][0], packed[k + 1][0], packed[k][1], packed[k + 1][1],
-                               B, h, w, cin, act=LRELU)
-                k += 2
-            else:
-                self.conv(ops, (cur, 0), (cur, nf8 + (k - 1) * gc8), packed[k][0], packed[k][1], B, h, w,
-                          cin, gc, act=LRELU)
-                k += 1
+        for k in range(1, 5):
+            self.conv(ops, (cur, 0), (cur, nf8 + (k - 1) * gc8), packed[k][0], packed[k][1], B, h, w,
+                      nf + (k - 1) * gc, gc, act=LRELU)
         wp, bp = self.fwd_layer(P, pre + "conv5")
         if q < 2:
             self.conv(ops, (cur, 0), dst, wp, bp, B, h, w, nf + 4 * gc, nf,
@@ -694,18 +623,9 @@ class _GenBase(Plan):
                 segs.append(dgrad_seg(W[k - 1], c0, src_off, s5 if k == 5 else 1.0))
                 c0 += W[k - 1].shape[0]
             dg[j] = (self.packed_layer(nf if j == 0 else gc, c0, 9, 0, segs, with_bias=False)[0], c0)
-        j = 4
-        while j >= 0:
+        for j in range(4, -1, -1):
             wp, c0 = dg[j]
             xin = (G, j * gc8)
-            if j >= 2 and self.pair_ok(w, c0, gc, gc):
-                # steps j and j-1 of the chain in one launch: step j-1 reads gy_j (this step's
-                # output, its FIRST input planes) and everything step j read
-                self.conv_pair(ops, xin, (G, (j - 1) * gc8), (G, (j - 2) * gc8), wp, dg[j - 1][0], 0, 0,
-                               B, h, w, c0, mask_a=(cur, nf8 + (j - 1) * gc8), mask_b=(cur, nf8 + (j - 2) * gc8),
-                               mask_slope=LRELU, a_out_first=True)
-                j -= 2
-                continue
             if j > 0:
                 self.conv(ops, xin, (G, (j - 1) * gc8), wp, 0, B, h, w, c0, gc,
                           mask=(cur, nf8 + (j - 1) * gc8), mask_slope=LRELU)
@@ -715,7 +635,6 @@ class _GenBase(Plan):
             else:
                 self.conv(ops, xin, dst, wp, 0, B, h, w, c0, nf, res1=(G, g8),
                           beta1=(RES if q == 2 else 1.0))
-            j -= 1
         # weight + bias gradients of the five convolutions: one launch per block, or deferred
         # into a single launch for the whole trunk (tasks then carry their own buffer pointers)
         tasks = []

@@ -127,59 +127,6 @@ def test_eight_wave_workgroup_shape_matches(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 40, 56), (3, 24, 33)])
-@pytest.mark.parametrize("mode", ["forward", "backward"])
-def test_conv_pair_matches_two_convs(shape, mode):
-    """srx_conv2d_pair against two srx_conv2d launches on the same buffers (bf16): forward form
-    (bias + LeakyReLU, A's output as B's last input channels) and data-gradient form (derivative
-    masks, A's output as B's first input channels), ragged image sizes included."""
-    E = pkg("engine")
-    B, H, W = shape
-    dev = torch.device("cuda")
-    cin_a = 64
-    torch.manual_seed(7)
-    res = []
-    for use_pair in (False, True):
-        plan = E.Plan(dev, torch.bfloat16)
-        buf = plan.buf(B, cin_a + 64, H, W, zero=True)            # [X | A | B] or [B | A | X]
-        msk = plan.buf(B, 64, H, W)
-        g = torch.Generator(device="cpu").manual_seed(11)
-        xin = torch.randn(B, cin_a, H, W, generator=g)
-        mk = torch.randn(B, 64, H, W, generator=g)
-        wa = torch.randn(32, cin_a, 3, 3, generator=g).cuda() * 0.05
-        wb = torch.randn(32, cin_a + 32, 3, 3, generator=g).cuda() * 0.05
-        ba = torch.randn(32, generator=g).cuda() * 0.1
-        bb = torch.randn(32, generator=g).cuda() * 0.1
-        fwd = mode == "forward"
-        x_oct = 0 if fwd else 8
-        a_oct, b_oct = (cin_a // 8, cin_a // 8 + 4) if fwd else (4, 0)
-        plan.nchw_to_c8(xin.cuda(), (buf, x_oct))
-        plan.nchw_to_c8(mk.cuda(), (msk, 0))
-        wpa, bpa = plan.packed_layer(32, cin_a, 9, 0, [E.conv_seg(wa)], ba.data_ptr() if fwd else 0, with_bias=fwd)
-        wpb, bpb = plan.packed_layer(32, cin_a + 32, 9, 0, [E.conv_seg(wb)], bb.data_ptr() if fwd else 0, with_bias=fwd)
-        plan.finalize_packing()
-        plan.run_packing()
-        ops = E.OpList()
-        kw_a = dict(act=0.2) if fwd else dict(mask=(msk, 4), mask_slope=0.2)
-        kw_b = dict(act=0.2) if fwd else dict(mask=(msk, 0), mask_slope=0.2)
-        b_in = (buf, 0) if fwd else (buf, 4)
-        if use_pair:
-            assert plan.pair_ok(W, cin_a, 32, 32, force=True)
-            plan.conv_pair(ops, (buf, x_oct), (buf, a_oct), (buf, b_oct), wpa, wpb, bpa, bpb, B, H, W, cin_a,
-                           act=0.2 if fwd else 1.0, mask_a=None if fwd else (msk, 4),
-                           mask_b=None if fwd else (msk, 0), mask_slope=0.2, a_out_first=not fwd)
-        else:
-            plan.conv(ops, (buf, x_oct), (buf, a_oct), wpa, bpa, B, H, W, cin_a, 32, **kw_a)
-            plan.conv(ops, b_in, (buf, b_oct), wpb, bpb, B, H, W, cin_a + 32, 32, **kw_b)
-        plan.run(plan.freeze(ops))
-        torch.cuda.synchronize()
-        res.append((plan.c8_to_nchw((buf, a_oct), 32).cpu(), plan.c8_to_nchw((buf, b_oct), 32).cpu()))
-    (a0, b0), (a1, b1) = res
-    assert float(a0.abs().max()) > 0 and float(b0.abs().max()) > 0
-    assert torch.equal(a0, a1)                                     # same arithmetic, same order
-    assert rel_err(b1, b0) < 1e-2                                  # bf16; accumulation order may differ
-
-
 def test_stream_create_priorities_and_side_stream():
     """srx_stream_create: a low- and a normal-priority stream run the same convolution to the same
     bits; a priority outside the device's range is an argument error; engine.side_stream hands out

@@ -115,30 +115,6 @@ def test_generator_23_bf16_forward_close():
     assert rel_l2(samp, ref) < 2e-2
 
 
-def test_graph_replay_matches_plain_launches():
-    """A plan replayed through srx_graph_capture / srx_graph_launch gives the results of plain
-    launches (third run on: first run plain, second captures)."""
-    E = pkg("engine")
-    G = pkg("esrgan.generator")
-    g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=3).cuda()
-    params = {n: p.data for n, p in g.named_parameters()}
-    x = O.hash_input("graph.x", (2, 3, 16, 16)).cuda()
-    gy = O.hash_input("graph.gy", (2, 3, 64, 64)).cuda()
-    outs = []
-    for use in (False, True):
-        plan = E.GeneratorPlan(params, 2, 16, 16, torch.float32, num_blocks=2, need_grad=True)
-        plan.use_graphs = use
-        for _ in range(3):
-            y = plan.forward(x)
-            plan.backward(gy)
-        torch.cuda.synchronize()
-        if use:
-            assert any(v for v in plan._graphs.values()), "no graph was captured"
-        outs.append((y.clone(), plan.flat_grad.clone()))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert rel_err(outs[1][1], outs[0][1]) < 1e-4          # weight gradients accumulate with atomics
-
-
 def test_config2_full_size_homogeneity_and_determinism():
     """Size-independent properties at the benchmark's full size (B=16, 64x64 LR, 23 blocks, bf16):
     with zero biases the generator is positively homogeneous (LeakyReLU and the residual
@@ -161,33 +137,6 @@ def test_config2_full_size_homogeneity_and_determinism():
     assert torch.isfinite(y1).all() and float(y1.abs().max()) > 0
     assert torch.equal(y1, y1b)
     assert torch.equal(y2, 2 * y1)
-
-
-def test_generator_with_pair_convolutions_matches_separate():
-    """The dense blocks run with fused convolution pairs (opt-in) give the forward output and
-    gradients of the default one-launch-per-convolution path (bf16, 32x32 patches)."""
-    E = pkg("engine")
-    G = pkg("esrgan.generator")
-    g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=3).cuda()
-    params = {n: p.data for n, p in g.named_parameters()}
-    x = O.hash_input("pair.x", (2, 3, 32, 32)).cuda()
-    gy = O.hash_input("pair.gy", (2, 3, 128, 128)).cuda() * 0.01
-    outs = []
-    for use in (False, True):
-        E.Plan.use_conv_pairs = use
-        try:
-            plan = E.GeneratorPlan(params, 2, 32, 32, torch.bfloat16, num_blocks=2, need_grad=True)
-        finally:
-            E.Plan.use_conv_pairs = False
-        names = [n for n, _ in plan.fwd_meta]
-        assert ("conv_pair_kernel<bf16>" in names) == use
-        y = plan.forward(x)
-        plan.backward(gy)
-        torch.cuda.synchronize()
-        outs.append((y.clone(), plan.flat_grad.clone()))
-    assert rel_err(outs[1][0], outs[0][0]) < 2e-2
-    cos = torch.nn.functional.cosine_similarity(outs[1][1], outs[0][1], dim=0)
-    assert float(cos) > 0.99
 
 
 def test_paired_weight_gradient_tasks_give_the_same_gradients():
