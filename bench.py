@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     ap.add_argument("--pair-wgrad-tasks", type=int, default=0,
                     help="pair the dense blocks' single-sub-block weight-gradient tasks (0/1)")
+    ap.add_argument("--deterministic-wgrad", type=int, default=0,
+                    help="weight gradients reduced in a fixed order (per-slice partials) instead of atomics (0/1)")
     ap.add_argument("--adam-in-backward", type=int, default=0,
                     help="single process: Adam applied range by range beside backward (0/1)")
     ap.add_argument("--from-host", action="store_true",
@@ -305,6 +307,7 @@ def main():
     if args.skip_wgrad:
         E.Plan.wgrad = lambda self, ops, *a, **k: None
     E.Plan.pair_wgrad_tasks = bool(args.pair_wgrad_tasks)
+    E.Plan.deterministic_wgrad = bool(args.deterministic_wgrad)
     T.GeneratorWarmupTrainer.step_in_backward = bool(args.adam_in_backward)
     T.AdversarialTrainer.step_in_backward = bool(args.adam_in_backward)
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)

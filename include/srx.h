@@ -154,6 +154,12 @@ typedef struct srx_wgrad_desc {
   int32_t nslices;       /* pixel-tile slices per task (grid = ntasks*nslices)      */
   int32_t group;         /* >1: tasks come in consecutive groups of this many that read the same
                             buffers; used to co-locate them on one XCD (speed only)  */
+  int64_t slice_stride;  /* 0: the pixel slices of a task ADD into the same tensors with fp32 atomics
+                            (the order of the adds, hence the last bits, varies from run to run).
+                            > 0, the deterministic form: slice s of every task STORES its partial
+                            sums at out[..] + s * slice_stride floats (bias_out likewise); the caller
+                            provides nslices zero-filled copies of the gradient tensors that far
+                            apart and srx_unpack_wgrad adds them up in slice order               */
 } srx_wgrad_desc;
 
 /* dW of nn.Conv2d (the autograd of esrgan/generator.py:10-14 etc.). */
@@ -162,6 +168,8 @@ int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream);
 /* tap-major fp32 [taps][Cout][Cin] -> PyTorch layout [Cout][Cin][taps], table driven. */
 typedef struct srx_unpack_item {
   const float* src; float* dst; int32_t cout, cin, taps; int32_t accumulate;
+  int32_t nslices;       /* > 1: src is the first of nslices partial tensors (srx_wgrad_desc.slice_stride */
+  int64_t slice_stride;  /*      floats apart), summed in slice order before the layout change          */
 } srx_unpack_item;
 int srx_unpack_wgrad(const srx_unpack_item* items /*DEVICE*/, int nitems, int64_t max_elems,
                      void* stream);

@@ -58,12 +58,12 @@ class WgradTask(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("dtype", i32), ("ksize", i32), ("stride", i32), ("B", i32), ("H", i32), ("W", i32),
                 ("x", vp), ("x_img_stride", i64), ("gy", vp), ("gy_img_stride", i64),
-                ("tasks", vp), ("ntasks", i32), ("nslices", i32), ("group", i32)]
+                ("tasks", vp), ("ntasks", i32), ("nslices", i32), ("group", i32), ("slice_stride", i64)]
 
 
 class UnpackItem(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("cout", i32), ("cin", i32), ("taps", i32),
-                ("accumulate", i32)]
+                ("accumulate", i32), ("nslices", i32), ("slice_stride", i64)]
 
 
 class SnLayer(C.Structure):

@@ -32,7 +32,8 @@ class _GradMixin:
         total = sum(P[n].numel() for n in names)
         self.flat_grad = flat_grad if flat_grad is not None else self.f32(total, zero=True)
         self.grads: Dict[str, torch.Tensor] = {}
-        self.stage = self.f32(total, zero=True)
+        self._stage_total = total
+        self.stage = self.f32(total * (self.det_slices if self.deterministic_wgrad else 1), zero=True)
         self._soff: Dict[str, int] = {}
         off = 0
         for n in names:
@@ -297,7 +298,10 @@ class DiscriminatorPlan(ChainPlan):
     def backward_c8(self) -> None:
         super().backward_c8()
         if self.need_param_grad:
-            L.check(self.lib.srx_sn_backward(self._snb_dev.data_ptr(), self.nl, self.unpack_max,
+            # (a launch sized for one element per layer sums <dW, W> in one workgroup, in a fixed
+            #  order: the deterministic form)
+            L.check(self.lib.srx_sn_backward(self._snb_dev.data_ptr(), self.nl,
+                                             1 if self.deterministic_wgrad else self.unpack_max,
                                              stream_ptr(self.device)), "srx_sn_backward")
 
     def input_grad(self) -> torch.Tensor:

@@ -177,14 +177,21 @@ __global__ void unpack_wgrad_kernel(const srx_unpack_item* __restrict__ items) {
   // source [tap][cout*cin] (tap-major staging), destination [cout*cin][tap] (nn.Conv2d layout).
   // A thread owns one (cout, cin) pair: its `taps` reads are coalesced across the wave (one per tap
   // plane), its writes are `taps` consecutive floats next to its neighbours'.
+  // With nslices > 1 the source is nslices partial tensors slice_stride floats apart (the
+  // deterministic weight-gradient form), added up in slice order: a fixed summation order.
   const srx_unpack_item it = items[blockIdx.y];
   const long plane = (long)it.cout * it.cin;
+  const int ns = it.nslices > 1 ? it.nslices : 1;
   for (long oc = blockIdx.x * (long)blockDim.x + threadIdx.x; oc < plane; oc += (long)gridDim.x * blockDim.x) {
     float* d = it.dst + oc * it.taps;
     if (it.taps == 9) {
       float v[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) v[t] = it.src[t * plane + oc];
+      for (int sl = 1; sl < ns; ++sl) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] += it.src[sl * it.slice_stride + t * plane + oc];
+      }
       if (it.accumulate) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] += d[t];
@@ -193,7 +200,8 @@ __global__ void unpack_wgrad_kernel(const srx_unpack_item* __restrict__ items) {
       for (int t = 0; t < 9; ++t) d[t] = v[t];
     } else {
       for (int t = 0; t < it.taps; ++t) {
-        const float v = it.src[t * plane + oc];
+        float v = it.src[t * plane + oc];
+        for (int sl = 1; sl < ns; ++sl) v += it.src[sl * it.slice_stride + t * plane + oc];
         d[t] = it.accumulate ? d[t] + v : v;
       }
     }

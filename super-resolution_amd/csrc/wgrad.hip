@@ -29,6 +29,7 @@ struct WgradParams {
   int H, W, OH, OW, B;
   int nslices, tiles_x, tiles_y;
   int group, ntasks;     // tasks per group (share x/gy buffers) for XCD-local ordering; 0 = off
+  long slice_stride;     // > 0: slice s stores its partial sums s * slice_stride floats further on
 };
 
 template <typename T> struct Frag;
@@ -350,13 +351,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   if (!active) return;
   const int col = lane & 31, hh = lane >> 5;
+  // deterministic form: every (task, slice) owns its own copy of the elements it produces, so a
+  // plain store replaces the atomic add and nothing depends on the order workgroups finish in
+  const bool det = p.slice_stride > 0;
+  const long sofs = det ? (long)slice * p.slice_stride : 0;
   if (biasp != nullptr && col == 0) {
     const int bn = tkp->bias_n[sb], b0 = tkp->bias_co0[sb];
     const float bs = tkp->bias_scale[sb];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = b0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (co < bn) atomicAdd(biasp + co, accb[i] * bs);
+      if (co < bn) {
+        if (det) biasp[sofs + co] = accb[i] * bs;
+        else atomicAdd(biasp + co, accb[i] * bs);
+      }
     }
   }
   const int ld = tkp->ld[sa + 2 * sb], co_n = tkp->co_n[sa + 2 * sb];
@@ -369,7 +377,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co_base + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (co < co_n) atomicAdd(outp + ((long)tap * co_n + co) * ld + ci, acc[tap][i] * scale);
+      if (co < co_n) {
+        float* const o = outp + sofs + ((long)tap * co_n + co) * ld + ci;
+        if (det) *o = acc[tap][i] * scale;
+        else atomicAdd(o, acc[tap][i] * scale);
+      }
     }
   }
 }
@@ -444,6 +456,8 @@ extern "C" int srx_conv2d_wgrad(const srx_wgrad_desc* d, void* stream) {
   p.nslices = d->nslices;
   p.tiles_x = p.tiles_y = 0;
   p.group = 0; p.ntasks = d->ntasks;
+  SRX_CHECK_ARG(d->slice_stride >= 0, "srx_conv2d_wgrad: negative slice_stride");
+  p.slice_stride = d->slice_stride;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == SRX_BF16 ? dispatch<bf16>(d, p, s) : dispatch<float>(d, p, s);
 }

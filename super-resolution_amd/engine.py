@@ -132,6 +132,8 @@ class Plan:
         self.dt = dtype_id(tdtype)
         self.esize = 2 if self.dt == L.BF16 else 4
         self.lib = L.lib()
+        self.deterministic_wgrad = bool(type(self).deterministic_wgrad)    # fixed when the plan is built
+        self._item_by_src = {}
         self.keep: List[torch.Tensor] = []
         self.pack_layers: List[L.PackLayer] = []
         self.pack_segs: List[L.PackSeg] = []
@@ -395,6 +397,16 @@ class Plan:
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
         d.nslices = nslices if nslices is not None else max(1, _ceil(target_blocks, len(tasks)))
         d.group = group
+        if self.deterministic_wgrad:
+            assert self._stage_total > 0, "deterministic weight gradients need the plan's staging buffer"
+            d.nslices = min(d.nslices, self.det_slices)
+            d.slice_stride = self._stage_total
+            # the unpack launch adds up as many copies of a tensor as the launches that fill it use
+            for t in tasks:
+                for e in list(t["sub"].values()) + list(t.get("bias", {}).values()):
+                    it = self._item_by_src.get(e["out"])
+                    if it is not None:
+                        it.nslices = max(it.nslices, d.nslices)
         ops.append(op)
         if isinstance(ops, OpList):
             pad = ksize // 2
@@ -410,10 +422,23 @@ class Plan:
 
     unpack_accumulate = 0    # 1: run_unpack adds into the destination gradients
 
+    # Deterministic weight gradients (opt-in): by default the pixel slices of a weight-gradient task
+    # add into one staging tensor with fp32 atomics, whose order — and so the last bits of the
+    # gradients — varies between runs.  With this set (before the plan is built), every slice
+    # stores into its own copy of the staging buffer and the unpack launch adds the copies in
+    # slice order: same inputs, same bits.  At most det_slices slices per task are then used
+    # (det_slices copies of the gradient-sized staging buffer).
+    deterministic_wgrad = False
+    det_slices = 32
+    _stage_total = 0
+
     def unpack_item(self, src_ptr: int, dst_ptr: int, cout: int, cin: int, taps: int):
         it = L.UnpackItem()
         it.src, it.dst, it.cout, it.cin, it.taps = src_ptr, dst_ptr, cout, cin, taps
         it.accumulate = self.unpack_accumulate
+        if self.deterministic_wgrad and self._stage_total > 0:
+            it.nslices, it.slice_stride = 1, self._stage_total
+            self._item_by_src[src_ptr] = it
         self.unpack_items.append(it)
         self.unpack_max = max(self.unpack_max, cout * cin * taps)
 
@@ -555,7 +580,8 @@ class _GenBase(Plan):
         self.flat_grad = flat_grad if flat_grad is not None else self.f32(total, zero=True)
         assert self.flat_grad.numel() >= total
         self.grads: Dict[str, torch.Tensor] = {}
-        self.stage = self.f32(total, zero=True)
+        self._stage_total = total
+        self.stage = self.f32(total * (self.det_slices if self.deterministic_wgrad else 1), zero=True)
         self._soff: Dict[str, int] = {}
         off = 0
         for n in self.param_names:

@@ -316,3 +316,63 @@ def test_config2_full_size_backward_directional_derivative():
     b = torch.cat([grads[n].flatten() for n in p16.param_names]).double()
     assert torch.isfinite(a).all()
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.97
+
+
+def test_deterministic_weight_gradients_same_bits_twice():
+    """Plan.deterministic_wgrad: every pixel slice stores its partial sums into its own copy of the
+    staging buffer and the unpack launch adds the copies in slice order, so two runs on the same
+    inputs give the same bits for every gradient (bf16 and fp32, the two-stream backward included),
+    and the values are those of the default atomic-add form up to summation order."""
+    E = pkg("engine")
+    G = pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=3), salt=23).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    x = O.hash_input("det.x", (4, 3, 40, 48)).cuda()
+    gy = O.hash_input("det.gy", (4, 3, 160, 192)).cuda() / (4 * 3 * 160 * 192)
+    for tdtype in (torch.bfloat16, torch.float32):
+        ref_plan = E.GeneratorPlan(params, 4, 40, 48, tdtype, num_blocks=3, need_grad=True)
+        ref_plan.forward(x)
+        ref_plan.backward(gy)
+        ref = ref_plan.flat_grad.clone()
+        E.Plan.deterministic_wgrad = True
+        try:
+            plan = E.GeneratorPlan(params, 4, 40, 48, tdtype, num_blocks=3, need_grad=True)
+        finally:
+            E.Plan.deterministic_wgrad = False
+        assert plan.stage.numel() == plan.det_slices * ref_plan.stage.numel()
+        assert max(it.nslices for it in plan.unpack_items) > 1
+        runs = []
+        for _ in range(3):
+            plan.forward(x)
+            plan.backward(gy)
+            torch.cuda.synchronize()
+            runs.append(plan.flat_grad.clone())
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2])
+        assert float(runs[0].abs().max()) > 0
+        assert rel_err(runs[0], ref) < 1e-5
+
+
+def test_deterministic_weight_gradients_discriminator():
+    E = pkg("engine")
+    CH = pkg("chain")
+    D = pkg("esrgan.discriminator")
+    d = fill_module_(D.Discriminator(), salt=6).cuda()
+    params = {n: p.data for n, p in d.named_parameters()}
+    bufs = {n: b.clone() for n, b in d.named_buffers()}
+    x = O.hash_input("detd.x", (4, 3, 64, 64)).cuda()
+    gl = torch.tensor([0.3, -0.2, 0.1, 0.25], device="cuda")
+    E.Plan.deterministic_wgrad = True
+    try:
+        plan = CH.DiscriminatorPlan(params, bufs, 4, 64, 64, torch.bfloat16, need_param_grad=True, need_input_grad=False)
+    finally:
+        E.Plan.deterministic_wgrad = False
+    runs = []
+    saved = {n: b.clone() for n, b in bufs.items()}
+    for _ in range(2):
+        for n, b in bufs.items():          # the power iteration advances u, v in place: same start for both runs
+            b.copy_(saved[n])
+        plan.forward_logits(x, training=True)
+        plan.backward(gl)
+        torch.cuda.synchronize()
+        runs.append(plan.flat_grad.clone())
+    assert torch.equal(runs[0], runs[1]) and float(runs[0].abs().max()) > 0
