@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     ap.add_argument("--pair-wgrad-tasks", type=int, default=0,
                     help="pair the dense blocks' single-sub-block weight-gradient tasks (0/1)")
+    ap.add_argument("--wgrad-walk-last", type=int, default=None,
+                    help="column-walk kernel for the last N trunk weight-gradient launches")
     ap.add_argument("--deterministic-wgrad", type=int, default=0,
                     help="weight gradients reduced in a fixed order (per-slice partials) instead of atomics (0/1)")
     ap.add_argument("--adam-in-backward", type=int, default=0,
@@ -313,6 +315,8 @@ def main():
     E.GeneratorPlan.overlap_wgrad = bool(args.wgrad_overlap)
     if args.wgrad_slices is not None:
         E.GeneratorPlan.trunk_wgrad_slices = args.wgrad_slices
+    if args.wgrad_walk_last is not None:
+        E.GeneratorPlan.trunk_wgrad_walk_last = args.wgrad_walk_last
     if args.wgrad_rdbs is not None:
         E.GeneratorPlan.trunk_wgrad_rdbs = args.wgrad_rdbs
     if adv:

@@ -2,7 +2,7 @@ import ctypes, importlib, sys, torch
 sys.path.insert(0, '.')
 L = importlib.import_module("super-resolution_amd._lib")
 if len(sys.argv) > 1 and sys.argv[1] != "base":
-    L.LIB_PATH = "scratch/libsrx_%s.so" % sys.argv[1]
+    L.LIB_PATH = "scratch/variants/libsrx_%s.so" % sys.argv[1]
 E = importlib.import_module("super-resolution_amd.engine")
 G = importlib.import_module("super-resolution_amd.esrgan.generator")
 dev = torch.device("cuda:0")
@@ -10,7 +10,7 @@ torch.manual_seed(0)
 gen = G.GeneratorESRGAN(num_blocks=23).to(dev)
 params = {n: p.data for n, p in gen.named_parameters()}
 import os
-E.Plan.pair_wgrad_tasks = bool(int(os.environ.get('PAIR', '1')))
+E.Plan.pair_wgrad_tasks = bool(int(os.environ.get("PAIR", "0")))
 E.GeneratorPlan.trunk_wgrad_slices = int(os.environ.get('SLICES', '4'))
 E.GeneratorPlan.trunk_wgrad_rdbs = int(os.environ.get('RDBS', '6'))
 plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, need_grad=True)

@@ -58,7 +58,8 @@ class WgradTask(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("dtype", i32), ("ksize", i32), ("stride", i32), ("B", i32), ("H", i32), ("W", i32),
                 ("x", vp), ("x_img_stride", i64), ("gy", vp), ("gy_img_stride", i64),
-                ("tasks", vp), ("ntasks", i32), ("nslices", i32), ("group", i32), ("slice_stride", i64)]
+                ("tasks", vp), ("ntasks", i32), ("nslices", i32), ("group", i32), ("tile_walk", i32), ("pad_", i32),
+                ("slice_stride", i64)]
 
 
 class UnpackItem(C.Structure):

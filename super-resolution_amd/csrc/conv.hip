@@ -47,24 +47,52 @@ __device__ __forceinline__ void mma(const f32x8& a, const f32x8& b, f32x16& c) {
   for (int s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
 }
 
-// Issue one chunk's LDS-DMA: NXS activation + NWS weight instructions per wave, no branches.
-template <typename T, int NXS, int NWS, int XPP, int THREADS>
+// Issue one chunk's LDS-DMA: DPC instructions per wave.  Wave instruction g = j * WAVES + wave of
+// the workgroup fills the 64 slots [64 g, 64 g + 64) of the stage: activation slots first (XPP of
+// them, a multiple of 64), weight slots behind.  An instruction is all activation or all weight;
+// only for the one j where the boundary falls between waves is the choice made at run time (a
+// wave-uniform branch).
+template <typename T, int DPC, int XPP, int THREADS>
 __device__ __forceinline__ void conv_issue_chunk(__amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc,
-                                                 const unsigned (&xoff)[NXS], const unsigned (&woff)[NWS],
-                                                 unsigned xcoff, unsigned wcoff, char* ls, int wave_u) {
+                                                 const unsigned* off, unsigned xcoff, unsigned wcoff,
+                                                 char* ls, int wave_u) {
   typedef __attribute__((address_space(3))) void lds_void;
   constexpr unsigned OOB = 0xFFFFFFF0u;
 #pragma unroll
-  for (int i = 0; i < NXS; ++i) {
-    const unsigned vo = xoff[i] == OOB ? OOB : xoff[i] + xcoff;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(ls + (i * THREADS + wave_u * 64) * 16), 16, vo, 0, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < NWS; ++i) {
-    const unsigned vo = woff[i] == OOB ? OOB : woff[i] + wcoff;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(ls + (XPP + i * THREADS + wave_u * 64) * 16), 16, vo, 0, 0, 0);
+  for (int j = 0; j < DPC; ++j) {
+    lds_void* dst = (lds_void*)(ls + (j * THREADS + wave_u * 64) * 16);
+    // (j is a constant after unrolling: the first two tests fold away)
+    if ((j + 1) * THREADS <= XPP) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dst, 16, off[j] == OOB ? OOB : off[j] + xcoff, 0, 0, 0);
+    } else if (j * THREADS >= XPP) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dst, 16, off[j] == OOB ? OOB : off[j] + wcoff, 0, 0, 0);
+    } else {
+      if (j * THREADS + wave_u * 64 < XPP)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dst, 16, off[j] == OOB ? OOB : off[j] + xcoff, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dst, 16, off[j] == OOB ? OOB : off[j] + wcoff, 0, 0, 0);
+    }
   }
 }
+
+// Stage geometry shared by the kernel and its launcher (16-byte slots).
+template <typename T, int STRIDE, int NB, int RW, int LTW, int KS, int WAVES, int CW>
+struct StageGeom {
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int TH = (WAVES / CW) * RW * (32 >> LTW);
+  static constexpr int IH = (TH - 1) * STRIDE + KS, IW = ((1 << LTW) - 1) * STRIDE + KS;
+  static constexpr int PPO = Oct<T>::PPO;
+  static constexpr int XP = 2 * IH * IW * PPO;                   // live activation slots
+  static constexpr int WP = NB * CW * KS * KS * 64 * PPO;        // live weight slots
+  // Regions padded to whole WORKGROUP instructions.  Padding them to whole wave instructions only
+  // (64 slots: 5 instead of 6 staging instructions per wave and chunk and 12 KB less LDS for the
+  // 32-channel dense-block shape) was built and measured: no faster stand-alone, and 1.3 ms per
+  // training step slower beside the weight-gradient workgroups of the other stream.
+  static constexpr int GRAN = THREADS;
+  static constexpr int XPP = (XP + GRAN - 1) / GRAN * GRAN, WPP = (WP + GRAN - 1) / GRAN * GRAN;
+  static constexpr int DPC = ((XPP + WPP) / 64 + WAVES - 1) / WAVES;           // instructions per wave and chunk
+  static constexpr int STAGE = DPC * THREADS;                    // slots per ring stage
+};
 
 // Workgroup shape.  WAVES waves = PW pixel groups of waves x CW output-block groups: a wave owns RW
 // groups of 32 pixels x NB blocks of 32 output channels; the workgroup stages NB*CW blocks of
@@ -97,15 +125,12 @@ void conv_kernel(const ConvParams p) {
   constexpr int NPIX = IH * IW;
   constexpr int PPO = Oct<T>::PPO;
   constexpr int EPP = 16 / sizeof(T);       // elements per 16-byte piece
-  constexpr int XP = 2 * NPIX * PPO;
-  constexpr int WP = NB * CW * TAPS * 64 * PPO;
-  constexpr int NXS = (XP + THREADS - 1) / THREADS;
-  constexpr int NWS = (WP + THREADS - 1) / THREADS;
-  constexpr int XPP = NXS * THREADS, WPP = NWS * THREADS;   // stage regions padded to whole workgroup instructions
-  constexpr int STAGE = XPP + WPP;          // 16-byte slots per ring stage
+  typedef StageGeom<T, STRIDE, NB, RW, LTW, KS, WAVES, CW> SG;
+  constexpr int XP = SG::XP, WP = SG::WP, XPP = SG::XPP;
+  constexpr int STAGE = SG::STAGE;          // 16-byte slots per ring stage
   constexpr int NSTG = RingDepth<T, NB, RW, WAVES, CW>::value;   // ring depth
   constexpr int DIST = NSTG - 1;            // chunks kept in flight ahead of the one being multiplied
-  constexpr int DMA_PER_CHUNK = NXS + NWS;  // LDS-DMA instructions each wave issues per chunk
+  constexpr int DMA_PER_CHUNK = SG::DPC;    // LDS-DMA instructions each wave issues per chunk
   static_assert(DMA_PER_CHUNK <= 31, "vmcnt budget");
   // consecutive row groups of a wave are consecutive image rows: activation fragments are shared
   // between tap rows (see the K loop)
@@ -140,18 +165,6 @@ void conv_kernel(const ConvParams p) {
   const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_is;
   const T* wb = reinterpret_cast<const T*>(p.w);
 
-  // The bias is the accumulators' initial value: a lane's 16 accumulator registers of block n
-  // are the packed-bias floats [(n*2+hh)*16, +16) (the packer's row order).  Loaded first, so
-  // these are the wave's oldest memory operations and have long landed when the loop starts.
-  f32x4 bias_v[NB][4];
-  if (p.bias) {
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        bias_v[n][k] = *reinterpret_cast<const f32x4*>(p.bias + ((nbw0 + n) * 2 + hh) * 16 + k * 4);
-  }
-
   // ---- staging plan: LDS-DMA ring ----
   // Every chunk (16 input channels: the halo tile of two octet planes + the 9-tap weight block)
   // goes global -> LDS by buffer_load ... lds, 16 bytes per lane, into one of NSTG ring stages;
@@ -169,33 +182,54 @@ void conv_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(wb + (long)nb0 * p.nchunk * (TAPS * 512)), 0,
       (int)((unsigned)(NB * CW) * p.nchunk * wchunk_bytes), 0x00020000);
-  unsigned xoff[NXS], woff[NWS];
-#pragma unroll
-  for (int i = 0; i < NXS; ++i) {
-    int piece = tid + i * THREADS;
-    int q = piece % PPO;
-    int pix = (piece / PPO) % NPIX;
-    int h = piece / (PPO * NPIX);
-    int r = pix / IW, c = pix % IW;
-    int gy = iy0 + r, gx = ix0 + c;
-    bool ok = piece < XP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+  // Set-up is ordered by what the first staging instructions need: a wave issues one instruction
+  // every few cycles and nothing overlaps this stretch, so every instruction in front of the
+  // first LDS-DMA is paid in full by every launch.  All selects are branch-free.
+  unsigned off[DMA_PER_CHUNK];
+  auto w_off = [&](unsigned piece) -> unsigned {      // piece: slot index inside the weight region
+    const unsigned nb = piece / (TAPS * 64 * PPO);
+    const unsigned rem = piece - nb * (TAPS * 64 * PPO);
+    return piece < (unsigned)WP ? nb * (unsigned)p.nchunk * wchunk_bytes + rem * 16u : OOB;
+  };
+  auto x_off = [&](unsigned piece) -> unsigned {      // piece: slot index inside the activation region
+    const unsigned q = piece % PPO;
+    const unsigned hp = piece / PPO;                  // (k half, pixel)
+    const unsigned h = hp / NPIX;
+    const unsigned pix = hp - h * NPIX;
+    const unsigned r = pix / IW, c = pix - r * IW;
+    const int gy = iy0 + (int)r, gx = ix0 + (int)c;
+    // unsigned compares fold the >= 0 tests in
+    const bool ok = (piece < (unsigned)XP) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    const unsigned o = h * plane_bytes + (unsigned)((gy * p.W + gx) * 8 + (int)(q * EPP)) * (unsigned)sizeof(T);
     // out-of-image slots stay out of range for every chunk: OOB minus the largest chunk offset
-    xoff[i] = ok ? (unsigned)h * plane_bytes + (unsigned)(((gy * p.W + gx) * 8 + q * EPP) * (int)sizeof(T))
-                 : OOB;
-  }
+    return ok ? o : OOB;
+  };
 #pragma unroll
-  for (int i = 0; i < NWS; ++i) {
-    int piece = tid + i * THREADS;
-    int nb = piece / (TAPS * 64 * PPO);
-    int rem = piece % (TAPS * 64 * PPO);
-    woff[i] = piece < WP ? (unsigned)nb * p.nchunk * wchunk_bytes + (unsigned)rem * 16u : OOB;
+  for (int j = 0; j < DMA_PER_CHUNK; ++j) {
+    const unsigned piece = (unsigned)tid + j * THREADS;
+    if ((j + 1) * THREADS <= XPP) off[j] = x_off(piece);
+    else if (j * THREADS >= XPP) off[j] = w_off(piece - XPP);
+    else off[j] = piece < (unsigned)XPP ? x_off(piece) : w_off(piece - XPP);
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int chunk, int stage) {
-    conv_issue_chunk<T, NXS, NWS, XPP, THREADS>(xrsrc, wrsrc, xoff, woff, (unsigned)chunk * 2u * plane_bytes,
-                                       (unsigned)chunk * wchunk_bytes,
-                                       reinterpret_cast<char*>(smem + stage * STAGE), wave_u);
+    conv_issue_chunk<T, DMA_PER_CHUNK, XPP, THREADS>(xrsrc, wrsrc, off, (unsigned)chunk * 2u * plane_bytes,
+                                                     (unsigned)chunk * wchunk_bytes,
+                                                     reinterpret_cast<char*>(smem + stage * STAGE), wave_u);
   };
+
+  // The bias is the accumulators' initial value: a lane's 16 accumulator registers of block n
+  // are the packed-bias floats [(n*2+hh)*16, +16) (the packer's row order).  Issued in front of
+  // the staging instructions, so they are the wave's oldest memory operations: the wait the
+  // compiler puts in front of their first use then leaves every staged chunk in flight.
+  f32x4 bias_v[NB][4];
+  if (p.bias) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        bias_v[n][k] = *reinterpret_cast<const f32x4*>(p.bias + ((nbw0 + n) * 2 + hh) * 16 + k * 4);
+  }
 
   // first chunks on their way before anything else is set up
 #pragma unroll
@@ -460,14 +494,11 @@ void conv_kernel(const ConvParams p) {
 
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS, int WAVES = 4, int CW = 1>
 int launch(const ConvParams& p0, int B, hipStream_t stream) {
-  constexpr int THREADS = 64 * WAVES;
+  typedef StageGeom<T, STRIDE, NB, RW, LTW, KS, WAVES, CW> SG;
+  constexpr int THREADS = SG::THREADS;
   constexpr int TW = 1 << LTW;
-  constexpr int TH = (WAVES / CW) * RW * (32 >> LTW);
-  constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-  constexpr int PPO = Oct<T>::PPO;
-  constexpr int XPP = ((2 * IH * IW * PPO + THREADS - 1) / THREADS) * THREADS;
-  constexpr int WPP = ((NB * CW * KS * KS * 64 * PPO + THREADS - 1) / THREADS) * THREADS;
-  constexpr int LDS = RingDepth<T, NB, RW, WAVES, CW>::value * (XPP + WPP) * 16;
+  constexpr int TH = SG::TH;
+  constexpr int LDS = RingDepth<T, NB, RW, WAVES, CW>::value * SG::STAGE * 16;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvParams p = p0;
   p.tiles_x = (p.OW + TW - 1) / TW;

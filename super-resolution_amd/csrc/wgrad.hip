@@ -18,6 +18,7 @@
 // fragments of an input row are read once and used by the three taps dy that map
 // it to an output row.  Octet planes in LDS are padded to 4 (mod 8) slots so the
 // transposed reads of a 32-lane half fall on 32 distinct 8-byte banks.
+#include <stdlib.h>
 #include "srx_common.h"
 
 namespace {
@@ -80,6 +81,48 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigne
                    (unsigned)__builtin_amdgcn_readfirstlane(rsrc[2]), (unsigned)__builtin_amdgcn_readfirstlane(rsrc[3])};
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(a), "v"(voffset), "s"(r) : "memory");
+}
+
+// The accumulators of one wave (9-tap 32x32 sub-block + bias column sums) into the task's
+// gradient tensors: fp32 atomic adds, or plain stores into the slice's own copy (deterministic form).
+template <int TAPS>
+__device__ __forceinline__ void wgrad_write_out(const WgradParams& p, const srx_wgrad_task* __restrict__ tkp,
+                                                int slice, int lane, int sa, int sb, float* outp, float* biasp,
+                                                const f32x16 (&acc)[TAPS], const f32x16& accb) {
+  const int col = lane & 31, hh = lane >> 5;
+  // deterministic form: every (task, slice) owns its own copy of the elements it produces, so a
+  // plain store replaces the atomic add and nothing depends on the order workgroups finish in
+  const bool det = p.slice_stride > 0;
+  const long sofs = det ? (long)slice * p.slice_stride : 0;
+  if (biasp != nullptr && col == 0) {
+    const int bn = tkp->bias_n[sb], b0 = tkp->bias_co0[sb];
+    const float bs = tkp->bias_scale[sb];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = b0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (co < bn) {
+        if (det) biasp[sofs + co] = accb[i] * bs;
+        else atomicAdd(biasp + co, accb[i] * bs);
+      }
+    }
+  }
+  const int ld = tkp->ld[sa + 2 * sb], co_n = tkp->co_n[sa + 2 * sb];
+  const int ci = tkp->ci0[sa + 2 * sb] + col;
+  const int co_base = tkp->co0[sa + 2 * sb];
+  const float scale = tkp->scale[sa + 2 * sb];
+  if (ci >= ld) return;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co_base + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (co < co_n) {
+        float* const o = outp + sofs + ((long)tap * co_n + co) * ld + ci;
+        if (det) *o = acc[tap][i] * scale;
+        else atomicAdd(o, acc[tap][i] * scale);
+      }
+    }
+  }
 }
 
 // Stage one tile (X halo tile + GY tile) into LDS stage `ls` by LDS-DMA.  A free function
@@ -350,40 +393,286 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 
   if (!active) return;
-  const int col = lane & 31, hh = lane >> 5;
-  // deterministic form: every (task, slice) owns its own copy of the elements it produces, so a
-  // plain store replaces the atomic add and nothing depends on the order workgroups finish in
-  const bool det = p.slice_stride > 0;
-  const long sofs = det ? (long)slice * p.slice_stride : 0;
-  if (biasp != nullptr && col == 0) {
-    const int bn = tkp->bias_n[sb], b0 = tkp->bias_co0[sb];
-    const float bs = tkp->bias_scale[sb];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = b0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (co < bn) {
-        if (det) biasp[sofs + co] = accb[i] * bs;
-        else atomicAdd(biasp + co, accb[i] * bs);
-      }
-    }
+  wgrad_write_out<TAPS>(p, tkp, slice, lane, sa, sb, outp, biasp, acc, accb);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Column walk: the 3x3 / stride-1 form for images at least 24 pixels wide.
+//
+// wgrad_kernel stages a whole halo tile per 128-pixel tile: (TH + 2) x 34 input pixels for TH x 32
+// output pixels, of which two rows were already staged for the tile above.  Here a workgroup walks
+// its tiles DOWN the image (tile order: image, tile column, tile row) and keeps the input rows in a
+// ring of three row groups of TH rows each: group k of a column holds input rows k*TH-1 ..
+// k*TH+TH-2; tile j multiplies with group j and the first two rows of group j+1, while group j+2
+// streams in.  Per tile one group (TH rows) is staged instead of TH+2 rows — a third less
+// activation traffic and staging instructions for TH = 4 — and the gradient tile goes in whole
+// 64-slot runs (no pad slots): 8.4 LDS-DMA instructions per wave and tile instead of 12.
+// A column costs one extra step (its first group has nothing to be multiplied with yet).
+template <typename T, int TPIX>
+__global__ __launch_bounds__(256) void wgrad_walk_kernel(const WgradParams p) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int TW = 32, TH = TPIX / 32, TAPS = 9;
+  constexpr int IH = TH + 2, IW = TW + 2;
+  constexpr int NPG = TH * IW;              // pixels of one row group
+  constexpr int PG = pad4mod8(NPG);         // LDS octet-plane stride (slots) inside a group
+  constexpr int PSG = pad4mod8(TPIX);       // ... of the GY tile
+  constexpr int PPO = Oct<T>::PPO;
+  constexpr int EPP = 16 / sizeof(T);
+  constexpr int OB = sizeof(T) * 8;         // bytes per octet slot
+  constexpr int XG = 8 * PG * PPO;          // 16-byte pieces per row group (incl. pads)
+  constexpr int GST = 8 * PSG * PPO;        // ... per GY stage
+  constexpr int NXS = (XG + 255) / 256;
+  constexpr int RPO = TPIX * PPO / 64;      // 64-piece runs per GY octet
+  constexpr int NGR = 8 * RPO / 4;          // GY runs per wave
+  static_assert(TH >= 2 && TPIX * PPO % 64 == 0 && (8 * RPO) % 4 == 0, "tile shape");
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [3 groups][2 GY stages]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int task_id, slice;
+  if (p.group > 0) {
+    const int gsz = p.group;
+    const int ngrp = (p.ntasks / gsz) * p.nslices;
+    const int super_ = blockIdx.x / (8 * gsz), r = blockIdx.x % (8 * gsz);
+    const int g = super_ * 8 + (r % 8), t = r / 8;
+    if (g >= ngrp) return;
+    task_id = (g / p.nslices) * gsz + t;
+    slice = g % p.nslices;
+  } else {
+    task_id = blockIdx.x / p.nslices;
+    slice = blockIdx.x % p.nslices;
   }
-  const int ld = tkp->ld[sa + 2 * sb], co_n = tkp->co_n[sa + 2 * sb];
-  const int ci = tkp->ci0[sa + 2 * sb] + col;
-  const int co_base = tkp->co0[sa + 2 * sb];
-  const float scale = tkp->scale[sa + 2 * sb];
-  if (ci >= ld) return;
+  const srx_wgrad_task* __restrict__ tkp = p.tasks + task_id;
+  const int sa = wave & 1, sb = wave >> 1;      // cin half, cout half
+  float* const outp = tkp->out[sa + 2 * sb];
+  float* const biasp = sa == 0 ? tkp->bias_out[sb] : nullptr;
+  const int x_noct = tkp->x_noct, gy_noct = tkp->gy_noct;
+  const int x_skip = tkp->x_skip, gy_skip = tkp->gy_skip;
+  const bool active = outp != nullptr;          // wave-uniform
+
+  const long plane_x = (long)p.H * p.W * 8;
+  const long plane_g = (long)p.OH * p.OW * 8;
+  const T* xbase = reinterpret_cast<const T*>(tkp->x ? tkp->x : p.x) + (long)tkp->x_oct * plane_x;
+  const T* gbase = reinterpret_cast<const T*>(tkp->gy ? tkp->gy : p.gy) + (long)tkp->gy_oct * plane_g;
+
+  // ---- per-lane LDS read addresses (bytes) relative to a group / GY stage, tap (0,0), k-step 0 ----
+  int ga[2], xa[2];
+  if constexpr (sizeof(T) == 2) {
+    const int gidx = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+    const int h = gidx >> 1;
+    const int osub = 2 * (gidx & 1) + (pq >> 1);
 #pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = co_base + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (co < co_n) {
-        float* const o = outp + sofs + ((long)tap * co_n + co) * ld + ci;
-        if (det) *o = acc[tap][i] * scale;
-        else atomicAdd(o, acc[tap][i] * scale);
-      }
+    for (int t = 0; t < 2; ++t) {
+      const int kp = 8 * h + 4 * t + q;        // pixel inside the 16-pixel k-step (one tile row)
+      ga[t] = ((4 * sb + osub) * PSG + kp) * OB + 8 * (pq & 1);
+      xa[t] = ((4 * sa + osub) * PG + kp) * OB + 8 * (pq & 1);
     }
+  } else {
+    const int r = lane & 31, h = lane >> 5;
+    ga[0] = ((4 * sb + (r >> 3)) * PSG + h) * OB + (r & 7) * 4;
+    xa[0] = ((4 * sa + (r >> 3)) * PG + h) * OB + (r & 7) * 4;
+    ga[1] = xa[1] = 0;
   }
+  auto load_g = [&](const char* sgb, int ks) -> frag_t {
+    const int gofs = ks * 16 * OB;
+    frag_t gf;
+    if constexpr (sizeof(T) == 2) {
+      gf = tr_frag(sgb, ga[0] + gofs, ga[1] + gofs);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) gf[s] = *reinterpret_cast<const float*>(sgb + ga[0] + gofs + 2 * s * OB);
+    }
+    return gf;
+  };
+  // X fragment whose 16 pixels start at (row, col) of the row group at sxg
+  auto load_x = [&](const char* sxg, int row, int col) -> frag_t {
+    const int xofs = (row * IW + col) * OB;
+    frag_t xf;
+    if constexpr (sizeof(T) == 2) {
+      xf = tr_frag(sxg, xa[0] + xofs, xa[1] + xofs);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xf[s] = *reinterpret_cast<const float*>(sxg + xa[0] + xofs + 2 * s * OB);
+    }
+    return xf;
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  f32x16 accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
+  frag_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
+
+  // ---- staging constants ----
+  const unsigned xplane_b = (unsigned)(plane_x * sizeof(T)), gplane_b = (unsigned)(plane_g * sizeof(T));
+  const int xbytes = (int)((unsigned)(x_noct + (x_noct > 4 ? x_skip : 0)) * xplane_b);
+  const int gbytes = (int)((unsigned)(gy_noct + (gy_noct > 4 ? gy_skip : 0)) * gplane_b);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned xoffs[NXS];
+  int xrc[NXS];
+#pragma unroll
+  for (int i = 0; i < NXS; ++i) {
+    const int slot = tid + i * 256;
+    const int q = slot % PPO, pix = (slot / PPO) % PG, o = slot / (PPO * PG);
+    const int r = pix / IW, c = pix % IW;
+    const bool live = slot < XG && pix < NPG && o < x_noct;
+    xoffs[i] = (unsigned)(o + (o >= 4 ? x_skip : 0)) * xplane_b + (unsigned)(((r * p.W + c) * 8 + q * EPP) * (int)sizeof(T));
+    xrc[i] = live ? (r | (c << 16)) : -1;
+  }
+  // GY: wave w stages the runs w, w+4, ...: run = (octet, 64-piece part of its TPIX*PPO pieces)
+  unsigned goffs[NGR];
+  int grc[NGR];
+#pragma unroll
+  for (int i = 0; i < NGR; ++i) {
+    const int run = wave + 4 * i;
+    const int o = run / RPO, piece = (run % RPO) * 64 + lane;
+    const int q = piece % PPO, pix = piece / PPO;
+    const int r = pix >> 5, c = pix & 31;
+    goffs[i] = (unsigned)(o + (o >= 4 ? gy_skip : 0)) * gplane_b + (unsigned)(((r * p.OW + c) * 8 + q * EPP) * (int)sizeof(T));
+    grc[i] = o < gy_noct ? (r | (c << 16)) : -1;
+  }
+  const unsigned lds_x0 = (unsigned)(unsigned long)smem;
+  const unsigned lds_g0 = lds_x0 + 3 * XG * 16;
+
+  // row group k of tile column (b, tx) -> ring slot
+  auto stage_group = [&](int b, int tx, int k, int ring) {
+    const int iy0 = k * TH - 1, ix0 = tx * TW - 1;
+    const long xoff_b = ((long)iy0 * p.W + ix0) * 8 * (long)sizeof(T);
+    const u32x4 xrs = make_rsrc(reinterpret_cast<const char*>(xbase + (long)b * p.x_is) + xoff_b,
+                                (unsigned)(xbytes - xoff_b));
+    const unsigned l0 = lds_x0 + ring * (XG * 16);
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const unsigned gy_ = (unsigned)(iy0 + (xrc[i] & 0xffff)), gx_ = (unsigned)(ix0 + (xrc[i] >> 16));
+      const bool ok = xrc[i] >= 0 && gy_ < (unsigned)p.H && gx_ < (unsigned)p.W;
+      if (NXS * 256 == XG || tid + i * 256 < XG)
+        lds_dma16(xrs, l0 + (i * 256 + wave_u * 64) * 16, ok ? xoffs[i] : OOB);
+    }
+  };
+  auto stage_gy = [&](int b, int tx, int ty, int gst) {
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const long goff_b = ((long)oy0 * p.OW + ox0) * 8 * (long)sizeof(T);
+    const u32x4 grs = make_rsrc(reinterpret_cast<const char*>(gbase + (long)b * p.gy_is) + goff_b,
+                                (unsigned)(gbytes - goff_b));
+    const unsigned l0 = lds_g0 + gst * (GST * 16);
+#pragma unroll
+    for (int i = 0; i < NGR; ++i) {
+      const int run = wave_u + 4 * i;
+      const unsigned oy = (unsigned)(oy0 + (grc[i] & 0xffff)), ox = (unsigned)(ox0 + (grc[i] >> 16));
+      const bool ok = grc[i] >= 0 && oy < (unsigned)p.OH && ox < (unsigned)p.OW;
+      lds_dma16(grs, l0 + ((run / RPO) * PSG * PPO + (run % RPO) * 64) * 16, ok ? goffs[i] : OOB);
+    }
+  };
+  // tile j of a column: row group ring slots ra (group j) and rb (group j+1), GY stage gst
+  auto compute = [&](int ra, int rb, int gst) {
+    const char* sga = reinterpret_cast<const char*>(smem) + ra * (XG * 16);
+    const char* sgb_x = reinterpret_cast<const char*>(smem) + rb * (XG * 16);
+    const char* sgy = reinterpret_cast<const char*>(smem) + 3 * XG * 16 + gst * (GST * 16);
+    constexpr int NC = TW / 16;           // k-steps per tile row
+    frag_t gf[TH][NC];
+#pragma unroll
+    for (int y = 0; y < TH; ++y)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) gf[y][c] = load_g(sgy, y * NC + c);
+    if (biasp != nullptr) {
+#pragma unroll
+      for (int y = 0; y < TH; ++y)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) mma(gf[y][c], ones, accb);
+    }
+#pragma unroll
+    for (int ry = 0; ry < IH; ++ry)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        frag_t xf[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          xf[dx] = ry < TH ? load_x(sga, ry, c * 16 + dx) : load_x(sgb_x, ry - TH, c * 16 + dx);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int y = ry - dy;
+          if (y >= 0 && y < TH) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) mma(gf[y][c], xf[dx], acc[dy * 3 + dx]);
+          }
+        }
+      }
+  };
+
+  // ---- the walk: tiles of this slice in (image, tile column, tile row) order ----
+  const int ncols = p.B * p.tiles_x;
+  const int ntiles = ncols * p.tiles_y;
+  const int per_slice = (ntiles + p.nslices - 1) / p.nslices;
+  int t = slice * per_slice;
+  const int t_end = t + per_slice < ntiles ? t + per_slice : ntiles;
+  int ring = 0;                              // ring slot of the group staged next
+  if (t < t_end) {
+    const int col = t / p.tiles_y;
+    stage_group(col / p.tiles_x, col % p.tiles_x, t % p.tiles_y, ring);
+  }
+  while (t < t_end) {
+    const int col = t / p.tiles_y, ty0 = t % p.tiles_y;
+    const int b = col / p.tiles_x, tx = col % p.tiles_x;
+    const int left = t_end - t;
+    const int n = p.tiles_y - ty0 < left ? p.tiles_y - ty0 : left;     // tiles of this column in the slice
+    // step j: group ty0+j has landed; stage group ty0+j+1 and the gradient tile of tile j; multiply
+    // tile j-1.  The last step stages the first group of the slice's next column instead.
+    for (int j = 0; j <= n; ++j) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // landed in every wave; every wave is done with the slot staged next
+      const int nxt = ring == 2 ? 0 : ring + 1;
+      if (j < n) {
+        stage_group(b, tx, ty0 + j + 1, nxt);
+        stage_gy(b, tx, ty0 + j, j & 1);
+      } else if (t + n < t_end) {
+        const int col2 = (t + n) / p.tiles_y;
+        stage_group(col2 / p.tiles_x, col2 % p.tiles_x, (t + n) % p.tiles_y, nxt);
+      }
+      if (j >= 1 && active) compute(ring == 0 ? 2 : ring - 1, ring, (j - 1) & 1);
+      ring = nxt;
+    }
+    t += n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!active) return;
+  wgrad_write_out<TAPS>(p, tkp, slice, lane, sa, sb, outp, biasp, acc, accb);
+}
+
+template <typename T, int TPIX>
+int launch_walk(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
+  constexpr int TH = TPIX / 32;
+  constexpr int PPO = Oct<T>::PPO;
+  constexpr int LDS = (3 * 8 * pad4mod8(TH * 34) + 2 * 8 * pad4mod8(TPIX)) * PPO * 16;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  p.tiles_x = (p.OW + 31) / 32;
+  p.tiles_y = (p.OH + TH - 1) / TH;
+  auto kern = wgrad_walk_kernel<T, TPIX>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  long ntiles = (long)p.B * p.tiles_x * p.tiles_y;
+  if (p.nslices > ntiles) p.nslices = (int)ntiles;
+  long grid = (long)d->ntasks * p.nslices;
+  p.group = 0; p.ntasks = d->ntasks;
+  if (d->group > 1 && d->ntasks % d->group == 0) {
+    p.group = d->group;
+    long ngrp = (long)(d->ntasks / d->group) * p.nslices;
+    grid = ((ngrp + 7) / 8) * 8 * d->group;
+  }
+  SRX_CHECK_ARG(grid > 0 && grid < (1L << 31), "wgrad grid out of range");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+  return srx_check_launch("wgrad_walk_kernel");
 }
 
 template <typename T, int STRIDE, int LTW, int KS, int TPIX>
@@ -417,11 +706,22 @@ int launch(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
   return srx_check_launch("wgrad_kernel");
 }
 
+// SRX_WGRAD_WALK=1 selects the column-walk kernel for every wide 3x3 stride-1 launch (A/B runs).
+static bool wgrad_walk_forced() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SRX_WGRAD_WALK");
+    v = e ? atoi(e) : 0;
+  }
+  return v != 0;
+}
+
 template <typename T>
 int dispatch(const srx_wgrad_desc* d, const WgradParams& p, hipStream_t s) {
   constexpr bool F = sizeof(T) == 4;
   if (d->ksize == 1) return launch<T, 1, 5, 1, 128>(d, p, s);
   if (d->stride == 1) {
+    if (p.OW >= 24 && (d->tile_walk || wgrad_walk_forced())) return launch_walk<T, F ? 64 : 128>(d, p, s);
     if (p.OW >= 24) return launch<T, 1, 5, 3, F ? 64 : 128>(d, p, s);
     if (p.OW >= 12) return launch<T, 1, 4, 3, F ? 64 : 128>(d, p, s);
     return launch<T, 1, 3, 3, F ? 64 : 128>(d, p, s);

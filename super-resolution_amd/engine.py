@@ -368,7 +368,7 @@ class Plan:
 
     def wgrad(self, ops: list, x: Optional[View], gy: Optional[View], tasks: List[dict], B: int, H: int, W: int, *,
               ksize=3, stride=1, target_blocks=512, nslices: Optional[int] = None,
-              x_img_stride: int = 0, gy_img_stride: int = 0, group: int = 0):
+              x_img_stride: int = 0, gy_img_stride: int = 0, group: int = 0, tile_walk: bool = False):
         arr = (L.WgradTask * len(tasks))()
         for i, t in enumerate(tasks):
             k = arr[i]
@@ -397,6 +397,7 @@ class Plan:
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
         d.nslices = nslices if nslices is not None else max(1, _ceil(target_blocks, len(tasks)))
         d.group = group
+        d.tile_walk = 1 if tile_walk else 0
         if self.deterministic_wgrad:
             assert self._stage_total > 0, "deterministic weight gradients need the plan's staging buffer"
             d.nslices = min(d.nslices, self.det_slices)
@@ -418,6 +419,8 @@ class Plan:
             tp = 128 if ksize == 1 else ((64 if f else 128) if stride == 1 else (32 if f else 64))
             name = "wgrad_kernel<%s,%d,%d,%d,%d>" % ("float" if f else "bf16", stride,
                                                      5 if ksize == 1 else ltw, ksize, tp)
+            if tile_walk and ksize == 3 and stride == 1 and OW >= 24:
+                name = "wgrad_walk_kernel<%s,%d>" % ("float" if f else "bf16", tp)
             ops.meta.append((name, 2.0 * B * OH * OW * ksize * ksize * pairs))
 
     unpack_accumulate = 0    # 1: run_unpack adds into the destination gradients
@@ -742,6 +745,12 @@ class GeneratorPlan(_GenBase):
     trunk_wgrad_slices = 4
     overlap_wgrad = True        # weight gradients on a side stream, beside the data-gradient chain
     trunk_wgrad_rdbs = 6        # dense blocks per weight-gradient launch in that mode (0: all in one)
+    # the last trunk weight-gradient launches run after the data-gradient chain has ended, alone on
+    # the chip, where the column-walk kernel is the faster one (beside the chain it is the slower)
+    # (None: by size — measured best: 2 launches at 64 K pixels per step, 8 from 256 K pixels on,
+    #  where the chain is far ahead of the weight gradients: -0.6 %, -4 % and -5 % per step at
+    #  16 x 64x64, 16 x 128x128 and 64 x 128x128)
+    trunk_wgrad_walk_last = None
 
     def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
                  *, in_ch=3, out_ch=3, nf=64, gc=32, num_blocks=23, need_grad=True,
@@ -882,8 +891,10 @@ class GeneratorPlan(_GenBase):
         pending_names: List[str] = []
         n_pending = 0
 
+        n_launches, launch_no = len(sizes), 0
+
         def flush():
-            nonlocal pending, pending_names, n_pending
+            nonlocal pending, pending_names, n_pending, launch_no
             if not pending:
                 return
             tasks, nblocks, names = pending, n_pending, pending_names
@@ -891,9 +902,15 @@ class GeneratorPlan(_GenBase):
             per_block = len(tasks) // nblocks
             # enough pixel slices to give every CU a workgroup, at least the configured number
             nsl = max(self.trunk_wgrad_slices, min(32, 256 // max(1, len(tasks))))
+            launch_no += 1
+            k_walk = self.trunk_wgrad_walk_last
+            if k_walk is None:
+                k_walk = 8 if B * h * w >= 200_000 else 2
+            walk = launch_no > n_launches - k_walk
             aside(lambda o: self.wgrad(o, None, None, tasks, B, h, w, nslices=nsl,
                                        x_img_stride=self.R[0].img_stride, gy_img_stride=self.G[0].img_stride,
-                                       group=per_block if per_block * nblocks == len(tasks) else 0), names)
+                                       group=per_block if per_block * nblocks == len(tasks) else 0,
+                                       tile_walk=walk), names)
 
         for r in range(nR - 1, -1, -1):
             blk, q = divmod(r, 3)

@@ -41,12 +41,16 @@ def _reference(case, tdtype):
     return x.detach(), w.detach(), gy, gx, gw, gb
 
 
+@pytest.mark.parametrize("walk", [False, True])
 @pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CASES)
-def test_wgrad_full_tensor(case, tdtype):
-    """dW and db of nn.Conv2d: every element, against autograd."""
+def test_wgrad_full_tensor(case, tdtype, walk):
+    """dW and db of nn.Conv2d: every element, against autograd; both kernels of the wide stride-1
+    shapes (whole halo tiles, and the column walk that keeps input rows in an LDS ring)."""
     E = pkg("engine")
     B, cin, cout, H, W, stride = case
+    if walk and (stride != 1 or W < 24):
+        pytest.skip("the column-walk kernel serves stride-1 launches on images at least 24 pixels wide")
     x, w, gy, _, gw_ref, gb_ref = _reference(case, tdtype)
     dev = torch.device("cuda")
     plan = E.Plan(dev, tdtype)
@@ -58,7 +62,10 @@ def test_wgrad_full_tensor(case, tdtype):
     dw, db = plan.f32(cout * cin * 9), plan.f32(cout)
     tasks = plan.wgrad_tasks_for_layer(cin, cout, 0, 0, stage_w.data_ptr(), bias_ptr=stage_b.data_ptr())
     ops = E.OpList()
-    plan.wgrad(ops, (X, 0), (GY, 0), tasks, B, H, W, ksize=3, stride=stride)
+    plan.wgrad(ops, (X, 0), (GY, 0), tasks, B, H, W, ksize=3, stride=stride, tile_walk=walk)
+    if walk:
+        # several slices, so that slices begin in the middle of tile columns too
+        ops[-1].u.wgrad.nslices = 7
     plan.unpack_item(stage_w.data_ptr(), dw.data_ptr(), cout, cin, 9)
     plan.unpack_item(stage_b.data_ptr(), db.data_ptr(), 1, cout, 1)
     plan.finalize_unpack()
