@@ -2,7 +2,7 @@ import ctypes, importlib, sys, torch
 sys.path.insert(0, '.')
 L = importlib.import_module("super-resolution_amd._lib")
 if len(sys.argv) > 1 and sys.argv[1] != "base":
-    L.LIB_PATH = "scratch/variants/libsrx_%s.so" % sys.argv[1]
+    L.LIB_PATH = "tools/variants/libsrx_%s.so" % sys.argv[1]
 E = importlib.import_module("super-resolution_amd.engine")
 G = importlib.import_module("super-resolution_amd.esrgan.generator")
 dev = torch.device("cuda:0")
