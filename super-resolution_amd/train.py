@@ -17,6 +17,7 @@ import torch
 from . import _lib as L
 from . import chain, engine
 from .parallel import broadcast_from_rank0
+from .utils import trace
 from .utils.flat import flatten_parameters
 
 
@@ -203,7 +204,12 @@ class GeneratorWarmupTrainer:
     step_in_backward = False
 
     def _sub_step(self, p, lr_img, hr_img):
-        Y = p.forward_c8(lr_img)
+        with trace.range_("generator forward"):
+            Y = p.forward_c8(lr_img)
+        with trace.range_("backward (+ gradient exchange)"):
+            return self._loss_and_backward(p, Y, hr_img)
+
+    def _loss_and_backward(self, p, Y, hr_img):
         L.check(p.lib.srx_l1_c8_nchw(p.dt, Y.ptr(), Y.img_stride, hr_img.data_ptr(), self.loss_acc.data_ptr(),
                                      p.GY.ptr(), p.GY.img_stride, 1.0 / self.n_streams, Y.B, p.out_ch, Y.H, Y.W,
                                      engine.stream_ptr(p.device)), "srx_l1_c8_nchw")
@@ -239,8 +245,10 @@ class GeneratorWarmupTrainer:
         g = self.plan.flat_grad
         if exchanged != "stepped":
             if self.grad_sync is not None and not exchanged:
-                self.grad_sync(g)
-            self.opt.step(g)
+                with trace.range_("gradient exchange"):
+                    self.grad_sync(g)
+            with trace.range_("optimizer"):
+                self.opt.step(g)
         self.steps += 1
 
     def mean_loss(self) -> float:
@@ -354,6 +362,7 @@ class AdversarialTrainer:
         sp = engine.stream_ptr(self.device)
         l_l1, l_adv, l_percep = self.lams
         vf, vr = self.v_fake, self.v_real
+        trace.push("generator forward + D(hr), VGG(hr)")
         if self.overlap_real_pass:
             # Everything that needs only the HR batch — D(hr) forward + backward and the VGG
             # features of hr — runs on the side stream under the generator's forward pass (a chain
@@ -375,6 +384,8 @@ class AdversarialTrainer:
             # ---- discriminator step (esrgan/train_esrgan.py:89-98)
             self._d_pass(self.d_real, hr_img, None, 1.0)
             fb = vr.forward_c8(hr_img, pack=False)
+        trace.pop()
+        trace.push("discriminator step")
         if self.overlap_real_pass:
             # the perceptual branch (VGG(fake) forward, L1 against VGG(hr), data gradient back to
             # fake) needs only Y: beside the discriminator step and the adversarial branch
@@ -390,6 +401,8 @@ class AdversarialTrainer:
         if self.grad_sync_d is not None:
             self.grad_sync_d(gd)
         self.opt_d.step(gd)
+        trace.pop()
+        trace.push("generator step")
         # ---- generator step (:102-111)
         dg = self.d_gen
         dg.A[0].t.copy_(Y.t)
@@ -415,6 +428,7 @@ class AdversarialTrainer:
             if self.grad_sync_g is not None and not exchanged:
                 self.grad_sync_g(gg)
             self.opt_g.step(gg)
+        trace.pop()
         self.steps += 1
 
     def losses(self) -> Dict[str, float]:

@@ -146,3 +146,20 @@ def test_row_permutation_is_a_bijection():
         return 8 * (2 * (i >> 3) + h) + (i & 7) if perm == 0 else 4 * (i & 7) + 2 * h + (i >> 3)
     for perm in (0, 1):
         assert sorted(row_to_chan(r, perm) for r in range(32)) == list(range(32))
+
+
+def test_roctx_ranges_are_off_by_default_and_switchable():
+    """utils.trace: ranges cost nothing unless enabled; enabling loads the ROCm marker library."""
+    T = pkg("utils.trace")
+    assert not T.enabled()
+    with T.range_("nothing"):        # no-op
+        pass
+    T.push("x"); T.pop()
+    T.enable(True)
+    try:
+        assert T.enabled()
+        with T.range_("phase"):
+            T.push("inner"); T.pop()
+    finally:
+        T.enable(False)
+    assert not T.enabled()
