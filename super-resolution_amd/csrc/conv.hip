@@ -33,6 +33,11 @@ struct ConvParams {
   int cin8, cout8, nchunk, nblk, ngroups;
   int tiles_x, tiles_y;
   int ps;
+  // XCD-aware workgroup -> tile map (0: off): workgroup L runs tile (L % 8) * remap_chunk + L / 8 for
+  // L < 8 * remap_chunk, decoded with the shifts lgx / lgy when the grid's x and y extents are
+  // powers of two (lgx >= 0), else by division
+  unsigned remap_chunk;
+  int lgx, lgy;
 };
 
 template <typename T> struct Frag;
@@ -153,9 +158,26 @@ void conv_kernel(const ConvParams p) {
   // grid = (tiles_x * ngroups, tiles_y, B): no run-time divisions on the way to the first load
   // in the common single-group case
   int tx = blockIdx.x, grp = 0;
+  int ty = blockIdx.y;
+  int b = blockIdx.z;
+  if (p.remap_chunk) {
+    // Workgroups go to the 8 XCDs round-robin in launch order.  Give each XCD a contiguous run of
+    // tiles instead of every eighth one: neighbouring tiles, which share halo rows and columns,
+    // then meet in one XCD's L2 instead of each fetching the halo from memory.
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned t = L < 8u * p.remap_chunk ? (L & 7u) * p.remap_chunk + (L >> 3) : L;
+    if (p.lgx >= 0) {
+      tx = (int)(t & ((1u << p.lgx) - 1u));
+      ty = (int)((t >> p.lgx) & ((1u << p.lgy) - 1u));
+      b = (int)(t >> (p.lgx + p.lgy));
+    } else {
+      const unsigned r = t / gridDim.x;
+      tx = (int)(t - r * gridDim.x);
+      b = (int)(r / gridDim.y);
+      ty = (int)(r - (unsigned)b * gridDim.y);
+    }
+  }
   if (p.ngroups > 1) { grp = tx % p.ngroups; tx /= p.ngroups; }
-  const int ty = blockIdx.y;
-  const int b = blockIdx.z;
   const int pg = wave % PW;                 // this wave's pixel group ...
   const int bg = wave / PW;                 // ... and output-block group inside the workgroup
   const int nb0 = grp * (NB * CW);          // first block staged by the workgroup
@@ -494,6 +516,16 @@ void conv_kernel(const ConvParams p) {
   }
 }
 
+// SRX_CONV_REMAP=0 keeps the launch-order tile map (A/B timing).
+static bool remap_off() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SRX_CONV_REMAP");
+    v = (e && atoi(e) == 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <typename T, int STRIDE, int NB, int RW, int LTW, int KS, int WAVES = 4, int CW = 1>
 int launch(const ConvParams& p0, int B, hipStream_t stream) {
   typedef StageGeom<T, STRIDE, NB, RW, LTW, KS, WAVES, CW> SG;
@@ -514,6 +546,19 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
     attr_set = true;
   }
   const long gx = (long)p.tiles_x * p.ngroups;
+  p.remap_chunk = 0; p.lgx = p.lgy = 0;
+  {
+    auto lg2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return (1L << l) == v ? l : -1; };
+    const int lx = lg2(gx), ly = lg2(p.tiles_y);
+    const long total = gx * p.tiles_y * B;
+    // (the division form costs every workgroup some sixty instructions in front of its first
+    //  load: only where a workgroup's lifetime dwarfs that)
+    if (total < (1L << 31) && !remap_off() && ((lx >= 0 && ly >= 0 && total >= 64) || total >= 1024)) {
+      p.remap_chunk = (unsigned)(total / 8);
+      p.lgx = (lx >= 0 && ly >= 0) ? lx : -1;
+      p.lgy = ly;
+    }
+  }
   SRX_CHECK_ARG(gx > 0 && gx < (1L << 31) && p.tiles_y > 0 && p.tiles_y <= 65535 && B <= 65535,
                 "conv grid out of range (%ld x %d x %d)", gx, p.tiles_y, B);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)p.tiles_y, (unsigned)B), dim3(THREADS), LDS, stream, p);

@@ -70,6 +70,33 @@ def test_conv3x3_large_image_dense_shapes(case, epilogue, tdtype):
     assert rel_err(out, ref) < TOL[tdtype]
 
 
+# Grids that take the XCD-aware workgroup -> tile map of the launcher: 64 or more workgroups with
+# power-of-two grid extents (shift decode; the second case has two output-block groups in grid x),
+# and 1 024 or more with ragged extents (division decode, 1 053 = 8 * 131 + 5: the last five
+# workgroups keep their launch-order tile).
+XCD_MAP_CASES = [
+    (4, 16, 32, 64, 64),
+    (2, 16, 128, 64, 64),
+    (9, 8, 32, 200, 288),
+]
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", XCD_MAP_CASES)
+def test_conv3x3_xcd_tile_map(case, tdtype):
+    B, cin, cout, H, W = case
+    x = O.hash_input(f"mx{case}", (B, cin, H, W))
+    w = O.hash_uniform(f"mw{case}", (cout, cin, 3, 3), (3.0 / (9 * cin)) ** 0.5)
+    b = O.hash_uniform(f"mb{case}", (cout,), 0.1)
+    ref = O.lrelu(O.conv3x3(x, w, b))
+    out = run_single_conv(x, w, b, tdtype=tdtype, act=0.2)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[tdtype]
+    # every image and tile separately: a wrong map would swap whole tiles between images
+    for bi in range(B):
+        assert rel_err(out[bi], ref[bi]) < 2 * TOL[tdtype]
+
+
 @pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
 def test_conv_residual_mask(tdtype):
     x = O.hash_input("xr", (2, 192, 10, 36))
