@@ -14,10 +14,14 @@ def bench(B, H, W, cin, cout, reps=100, dt=torch.bfloat16):
     for x in X:
         x.t.normal_()
     Y = plan.buf(B, cout, H, W)
-    wp, bp = plan.packed_layer(cout, cin, 9, 0, [E.conv_seg(w)], bias.data_ptr())
+    # MB_WEIGHT_SETS=n: rotate among n packed copies of the weights (every launch of a real layer
+    # chain reads weights no earlier launch has touched)
+    nw = int(os.environ.get("MB_WEIGHT_SETS", "1"))
+    packed = [plan.packed_layer(cout, cin, 9, 0, [E.conv_seg(w)], bias.data_ptr()) for _ in range(nw)]
     plan.finalize_packing(); plan.run_packing()
     ops = []
     for i in range(reps):
+        wp, bp = packed[i % nw]
         plan.conv(ops, (X[i % 8], 0), (Y, 0), wp, bp, B, H, W, cin, cout, act=0.2)
     fr = plan.freeze(ops)
     plan.run(fr); torch.cuda.synchronize()
