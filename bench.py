@@ -169,11 +169,77 @@ def child_commands(args_list, n, port):
     return cmds
 
 
+def _tail(path, nbytes=2000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            f.seek(max(0, f.tell() - nbytes))
+            return f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def supervise_ranks(cmds, rank_timeout, poll_s=0.1, grace_s=5.0, log_dir=None):
+    """Start one fresh process per (argv, environment additions) entry and watch all of them.
+
+    Every rank's stdout and stderr go to files of their own (rank<r>.out / rank<r>.err under
+    log_dir, a temporary directory by default).  The first rank that exits non-zero, or the
+    group running past rank_timeout seconds, ends the job: the remaining ranks (which would
+    otherwise sit in the rendezvous or in a collective until some outer limit) are terminated,
+    then killed after grace_s, and each rank's stderr tail is written to this process's stderr.
+    Returns (exit code, rank 0's stdout): 0 only if every rank exited 0."""
+    import subprocess
+    import tempfile
+    log_dir = log_dir or tempfile.mkdtemp(prefix="bench_ranks_")
+    procs, files = [], []
+    for r, (argv, env) in enumerate(cmds):
+        fo = open(os.path.join(log_dir, f"rank{r}.out"), "wb")
+        fe = open(os.path.join(log_dir, f"rank{r}.err"), "wb")
+        files += [fo, fe]
+        procs.append(subprocess.Popen(argv, env=dict(os.environ, **env), stdout=fo, stderr=fe))
+    t0 = time.monotonic()
+    why = None
+    while why is None:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why = f"rank {bad[0]} exited with code {rcs[bad[0]]}"
+        elif all(rc == 0 for rc in rcs):
+            break
+        elif time.monotonic() - t0 > rank_timeout:
+            why = f"ranks still running after --rank-timeout {rank_timeout:g} s"
+        else:
+            time.sleep(poll_s)
+    if why is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < grace_s:
+            time.sleep(poll_s)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    for f in files:
+        f.close()
+    out0 = _tail(os.path.join(log_dir, "rank0.out"), 1 << 20)
+    if why is None:
+        return 0, out0
+    sys.stderr.write(f"bench.py: {why}; the other ranks were stopped (logs: {log_dir})\n")
+    for r, p in enumerate(procs):
+        sys.stderr.write(f"--- rank {r} (exit code {p.returncode}) stderr tail ---\n"
+                         + _tail(os.path.join(log_dir, f"rank{r}.err")) + "\n")
+    sys.stderr.flush()
+    return 1, out0
+
+
 def self_launch(args, argv):
     """--gpus N without a launcher: start N fresh rank processes (before this process has made
-    any GPU call), forward rank 0's JSON line, fail if any rank fails."""
+    any GPU call), forward rank 0's JSON line; a rank that fails, or the group running past
+    --rank-timeout, ends the job with a non-zero exit code and every rank's stderr tail."""
     import socket
-    import subprocess
     port = args.master_port
     if not port:
         with socket.socket() as s_:
@@ -187,15 +253,10 @@ def self_launch(args, argv):
     if ngpu < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {ngpu} GPU(s); one rank per GPU is "
                          f"required (RCCL does not run two ranks on one device)")
-    procs = []
-    for r, (c, e) in enumerate(cmds):
-        procs.append(subprocess.Popen(c, env=dict(os.environ, **e),
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    rc, out0 = supervise_ranks(cmds, args.rank_timeout)
     sys.stdout.write(out0)
     sys.stdout.flush()
-    return 0 if all(rc == 0 for rc in rcs) else 1
+    return rc
 
 
 def bench_inference(args, dev, rank, world):
@@ -265,6 +326,9 @@ def main():
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no launcher: print the rank commands instead of starting them")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0: a free one)")
+    ap.add_argument("--rank-timeout", type=float, default=540.0,
+                    help="with --gpus N > 1 and no launcher: seconds after which ranks that are still running are "
+                         "stopped and the job fails (a rank that exits non-zero stops the others at once)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -39,6 +39,10 @@ const char* srx_last_error(void);
  * 2 srx_wgrad_desc, 3 srx_pack_seg, 4 srx_pack_layer, 5 srx_unpack_item, 6 srx_sn_layer,
  * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop; -1 for an unknown id. */
 int srx_sizeof(int which);
+/* Host-side self-check (no GPU call): kernel attributes such as the dynamic LDS limit are set
+ * once per DEVICE a kernel is launched on, not once per process.  0 = ok.  No counterpart in the
+ * reference (single device, config.py:54). */
+int srx_selftest_per_device_once(void);
 
 /* ------------------------------------------------------------------ layout */
 /* NCHW fp32 -> C8 (dtype), zero-filling the padding slots of the last octet.

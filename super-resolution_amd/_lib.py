@@ -104,6 +104,7 @@ _SIGS = {
     "srx_version": (C.c_int, []),
     "srx_last_error": (C.c_char_p, []),
     "srx_sizeof": (C.c_int, [C.c_int]),
+    "srx_selftest_per_device_once": (C.c_int, []),
     "srx_nchw_to_c8": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "srx_c8_to_nchw": (C.c_int, [C.c_int, vp, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "srx_pack_weights": (C.c_int, [C.c_int, vp, vp, C.c_int, i64, vp]),

@@ -38,6 +38,33 @@ int srx_sizeof(int which) {
   }
 }
 
+namespace {
+int selftest_calls = 0;
+int selftest_set(void* arg) {
+  ++selftest_calls;
+  return *static_cast<int*>(arg);      // the status the "attribute call" is to return
+}
+}  // namespace
+
+int srx_selftest_per_device_once(void) {
+  // the bookkeeping behind hipFuncSetAttribute(MaxDynamicSharedMemorySize): the setter must run
+  // once for EVERY device a kernel is launched on (not once per process), again after a failure,
+  // and never for an out-of-range device index.  No GPU call is made.
+  static srx_per_device_once flags;
+  for (int d = 0; d < SRX_MAX_DEVICES; ++d) flags.done[d] = 0;
+  selftest_calls = 0;
+  int ok = SRX_OK, fail = SRX_ERR_HIP;
+  const int seq[] = {0, 1, 0, 1, 7, 0, 7};
+  for (int d : seq)
+    if (srx_once_per_device(&flags, d, selftest_set, &ok) != SRX_OK) return -1;
+  if (selftest_calls != 3) return -2;                          // devices 0, 1, 7: once each
+  if (srx_once_per_device(&flags, 3, selftest_set, &fail) != SRX_ERR_HIP) return -3;
+  if (srx_once_per_device(&flags, 3, selftest_set, &ok) != SRX_OK || selftest_calls != 5) return -4;   // retried
+  if (srx_once_per_device(&flags, SRX_MAX_DEVICES, selftest_set, &ok) != SRX_ERR_INVALID) return -5;
+  if (srx_once_per_device(&flags, -1, selftest_set, &ok) != SRX_ERR_INVALID || selftest_calls != 5) return -6;
+  return 0;
+}
+
 int srx_run_ops(const srx_op* ops, int n, void* stream) {
   SRX_CHECK_ARG(ops != nullptr && n >= 0, "srx_run_ops: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

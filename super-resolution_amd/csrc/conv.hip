@@ -539,12 +539,8 @@ int launch(const ConvParams& p0, int B, hipStream_t stream) {
   p.tiles_y = (p.OH + TH - 1) / TH;
   p.ngroups = p.nblk / (NB * CW);
   auto kern = conv_kernel<T, STRIDE, NB, RW, LTW, KS, WAVES, CW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  static srx_per_device_once attr_set;     // per instantiation, per device
+  if (int rc = srx_ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(kern), LDS)) return rc;
   const long gx = (long)p.tiles_x * p.ngroups;
   p.remap_chunk = 0; p.lgx = p.lgy = 0;
   {

@@ -31,6 +31,36 @@ void srx_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// A kernel attribute (the dynamic LDS limit) belongs to ONE device's copy of the kernel:
+// hipFuncSetAttribute applies to the device that is current when it is called.  One flag per
+// device, one array per kernel instantiation (a function-local static of its launcher).
+#define SRX_MAX_DEVICES 64
+struct srx_per_device_once {
+  unsigned char done[SRX_MAX_DEVICES];    // zero-initialised (static storage)
+};
+// Runs set(arg) the first time it is called for `device` with this flag set; SRX_OK afterwards.
+// Two threads racing on a device's first launch both run set(): it is idempotent.
+static inline int srx_once_per_device(srx_per_device_once* flags, int device, int (*set)(void*), void* arg) {
+  SRX_CHECK_ARG(device >= 0 && device < SRX_MAX_DEVICES, "device index %d out of range [0, %d)", device, SRX_MAX_DEVICES);
+  if (__atomic_load_n(&flags->done[device], __ATOMIC_ACQUIRE)) return SRX_OK;
+  const int rc = set(arg);
+  if (rc == SRX_OK) __atomic_store_n(&flags->done[device], (unsigned char)1, __ATOMIC_RELEASE);
+  return rc;
+}
+struct srx_lds_attr { const void* kern; int bytes; };
+static inline int srx_set_lds_attr(void* a) {
+  const srx_lds_attr* s = static_cast<const srx_lds_attr*>(a);
+  SRX_CHECK_HIP(hipFuncSetAttribute(s->kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->bytes));
+  return SRX_OK;
+}
+// The dynamic LDS limit of `kern` on the current device, set once per device.
+static inline int srx_ensure_dynamic_lds(srx_per_device_once* flags, const void* kern, int bytes) {
+  int dev = 0;
+  SRX_CHECK_HIP(hipGetDevice(&dev));
+  srx_lds_attr a = {kern, bytes};
+  return srx_once_per_device(flags, dev, srx_set_lds_attr, &a);
+}
+
 static inline int srx_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -655,12 +655,8 @@ int launch_walk(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
   p.tiles_x = (p.OW + 31) / 32;
   p.tiles_y = (p.OH + TH - 1) / TH;
   auto kern = wgrad_walk_kernel<T, TPIX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  static srx_per_device_once attr_set;     // per instantiation, per device
+  if (int rc = srx_ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(kern), LDS)) return rc;
   long ntiles = (long)p.B * p.tiles_x * p.tiles_y;
   if (p.nslices > ntiles) p.nslices = (int)ntiles;
   long grid = (long)d->ntasks * p.nslices;
@@ -686,12 +682,8 @@ int launch(const srx_wgrad_desc* d, WgradParams p, hipStream_t stream) {
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + TH - 1) / TH;
   auto kern = wgrad_kernel<T, STRIDE, LTW, KS, TPIX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  static srx_per_device_once attr_set;     // per instantiation, per device
+  if (int rc = srx_ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(kern), LDS)) return rc;
   long ntiles = (long)p.B * p.tiles_x * p.tiles_y;
   if (p.nslices > ntiles) p.nslices = (int)ntiles;
   long grid = (long)d->ntasks * p.nslices;

@@ -47,3 +47,48 @@ def test_host_cpu_info_reads_this_machine():
     assert isinstance(model, str) and model
     assert logical and logical >= 1
     assert physical is None or 1 <= physical <= logical
+
+
+def _fake_ranks(*bodies):
+    return [([sys.executable, "-c", b], {"RANK": str(r)}) for r, b in enumerate(bodies)]
+
+
+def test_a_failing_rank_stops_the_others_within_seconds(tmp_path, capsys):
+    """--gpus N started by bench.py itself: one rank that dies must not leave the others waiting in
+    a rendezvous or a collective until an outer limit; the parent reports it and returns non-zero."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    cmds = _fake_ranks("import time; print('rank0 up', flush=True); time.sleep(120)",
+                       "import sys; sys.stderr.write('boom from rank 1\\n'); sys.exit(3)",
+                       "import time; time.sleep(120)")
+    t0 = time.monotonic()
+    rc, out0 = bench.supervise_ranks(cmds, rank_timeout=60.0, grace_s=2.0, log_dir=str(tmp_path))
+    assert rc != 0
+    assert time.monotonic() - t0 < 15.0
+    assert "rank0 up" in out0
+    err = capsys.readouterr().err
+    assert "rank 1 exited with code 3" in err and "boom from rank 1" in err
+    assert (tmp_path / "rank2.err").exists()
+
+
+def test_ranks_that_hang_are_stopped_at_the_rank_timeout(tmp_path, capsys):
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    # rank 1 ignores SIGTERM: it must be killed after the grace period
+    cmds = _fake_ranks("import time; time.sleep(120)",
+                       "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(120)")
+    t0 = time.monotonic()
+    rc, _ = bench.supervise_ranks(cmds, rank_timeout=1.0, grace_s=1.0, log_dir=str(tmp_path))
+    assert rc != 0
+    assert time.monotonic() - t0 < 15.0
+    assert "--rank-timeout" in capsys.readouterr().err
+
+
+def test_all_ranks_ok_forwards_rank0_stdout(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    rc, out0 = bench.supervise_ranks(_fake_ranks("print('{\"value\": 1}')", "print('ignored')"), rank_timeout=30.0,
+                                     log_dir=str(tmp_path))
+    assert rc == 0 and out0.strip() == '{"value": 1}'

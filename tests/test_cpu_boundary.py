@@ -38,6 +38,13 @@ def test_binding_struct_sizes_match_library():
     assert lib.srx_sizeof(99) == -1
 
 
+def test_kernel_attributes_are_kept_per_device():
+    """The dynamic-LDS attribute of a kernel is set once for every device it is launched on (a
+    process that drives two GPUs must not skip the second), again after a failed attempt, and
+    never indexed out of range: the library's own host-side check of that bookkeeping."""
+    assert pkg("_lib").lib().srx_selftest_per_device_once() == 0
+
+
 def test_argument_errors_are_reported_not_thrown():
     L = pkg("_lib")
     lib = L.lib()
