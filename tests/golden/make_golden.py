@@ -227,6 +227,28 @@ arrays["d_logits_128"] = d(x128).detach().numpy()
 case("d128", salt=4, x="hash_input('d.x128',[2,3,128,128])", logits="d_logits_128",
      note="first train-mode forward from the salt-4 state", pinned_by="reference")
 
+# 128x128 with backward (config 3's real map sizes: 128, 64, 32, 16, 8 pixels a side,
+# esrgan/discriminator.py:18-25): BCE against ones, whole gradient tensors, input gradient, u / v after
+fill_module_(d, salt=4)
+d.zero_grad(set_to_none=True)
+x128g = O.hash_input("d.x128", (2, 3, 128, 128)).requires_grad_(True)
+l128 = d(x128g)
+assert torch.equal(l128.detach(), torch.from_numpy(arrays["d_logits_128"]))
+loss128 = torch.nn.BCEWithLogitsLoss()(l128, torch.ones_like(l128))
+loss128.backward()
+arrays["d128_gx"] = x128g.grad.numpy().copy()
+for k in ("features.0.0", "features.6.0", "classifier.3"):
+    for s in ("weight_u", "weight_v"):
+        arrays[f"d128_after1_{k}.{s}"] = d.state_dict()[f"{k}.{s}"].numpy().copy()
+case("d128_bwd", salt=4, x="hash_input('d.x128',[2,3,128,128])", loss="BCE(D(x),1)", loss_value=float(loss128),
+     gx="d128_gx", grads=grad_summary(d.named_parameters()),
+     full_grads=full_grads("d128", d.named_parameters(),
+                           ["features.0.0.weight_orig", "features.0.0.bias", "features.3.0.weight_orig",
+                            "features.6.0.weight_orig", "classifier.1.weight_orig", "classifier.3.weight_orig"],
+                           steps={"features.6.0.weight_orig": 16, "classifier.1.weight_orig": 8}),
+     note="first train-mode forward from the salt-4 state, then backward", pinned_by="reference")
+d.zero_grad(set_to_none=True)
+
 # ---------------------------------------------------------------- SN backward identity (fp64)
 w = O.hash_uniform("sn.w", (6, 4, 3, 3)).double().requires_grad_(True)
 u = torch.nn.functional.normalize(O.hash_uniform("sn.u", (6,)).double(), dim=0)

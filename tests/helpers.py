@@ -48,6 +48,19 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
 TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
 
 
+def record_observed(test: str, **values) -> None:
+    """Append the error figures a test observed to gpurun_out/observed_errors.jsonl (when that
+    directory exists: the GPU box's scratch output), so that tolerances can be stated next to what
+    was measured.  Never fails a test."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "observed_errors.jsonl"), "a") as f:
+                f.write(json.dumps({"test": test, **{k: float(v) for k, v in values.items()}}) + "\n")
+    except (OSError, TypeError, ValueError):
+        pass
+
+
 def full_grads_bad(named_grads, index, arr, tol):
     """Element-wise comparison of whole gradient tensors against the reference's (the
     `full_grads` index of a golden case): returns [(name, rel L2, rel max)] of the tensors whose

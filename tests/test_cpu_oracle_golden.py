@@ -110,6 +110,31 @@ def test_discriminator_and_spectral_norm_match_reference():
     assert rel_err(le, torch.from_numpy(arr["d_logits_eval"])) < 1e-5
 
 
+def test_discriminator_128_backward_matches_reference():
+    """The discriminator at the reference's default HR crop (128 x 128, config.py:40-44): logits,
+    BCE backward (whole gradient tensors, input gradient) and u / v after the pass."""
+    man, arr = golden()
+    case = man["cases"]["d128_bwd"]
+    sd = _sd(O.discriminator_state_dict_spec(), 4)
+    state = {k: v.clone() for k, v in sd.items() if k.endswith(("weight_u", "weight_v"))}
+    for k in sd:
+        if k.endswith(("bias", "weight_orig")):
+            sd[k].requires_grad_(True)
+    x = O.hash_input("d.x128", (2, 3, 128, 128)).requires_grad_(True)
+    out = O.discriminator_forward(x, sd, True, state)
+    assert rel_err(out, torch.from_numpy(arr["d_logits_128"])) < 1e-5
+    loss = O.bce_with_logits(out, 1.0)
+    assert abs(float(loss) - case["loss_value"]) < 1e-6
+    loss.backward()
+    assert rel_err(x.grad, torch.from_numpy(arr["d128_gx"])) < 1e-4
+    for n, ent in case["full_grads"].items():
+        ref = torch.from_numpy(arr[ent["array"]]).flatten()
+        assert rel_err(sd[n].grad.flatten()[::ent["step"]], ref) < 1e-4, n
+    for k in ("features.0.0", "features.6.0", "classifier.3"):
+        for s_ in ("weight_u", "weight_v"):
+            assert rel_err(state[f"{k}.{s_}"], torch.from_numpy(arr[f"d128_after1_{k}.{s_}"])) < 1e-5
+
+
 def test_sn_backward_rank_one_identity():
     """dW_orig = dW_sn/sigma - (<dW_sn, W_orig>/sigma^2) u v^T  (what srx_sn_backward computes)."""
     w = O.hash_uniform("sn.w", (6, 4, 3, 3)).double().requires_grad_(True)

@@ -3,10 +3,17 @@ step (drop-in modules through the C ABI) against the reference-generated goldens
 import pytest
 import torch
 
-from helpers import O, TOL, fill_module_, full_grads_bad, golden, pkg, rel_err, rel_l2
+from helpers import O, TOL, fill_module_, full_grads_bad, golden, pkg, record_observed, rel_err, rel_l2
 from test_gpu_generator import _grads_close
 
 pytestmark = pytest.mark.gpu
+
+# fp32 gradients that pass through sign() (L1) and ReLU / LeakyReLU derivatives on tiny fixtures
+# (2 x 16x16 LR): one rounding-level sign flip would move a tensor by O(1/pixels).  Observed on MI355X:
+# 2.2e-6 relative L2 on every tensor (profiles/r3_observed_parity_errors.json), so the bar is the
+# fp32 tolerance of the whole path, 1e-3.
+VGG_GRAD_FP32_TOL = 1e-3
+ADV_G_GRAD_FP32_TOL = 1e-3
 
 
 def _disc(salt, tdtype):
@@ -75,6 +82,73 @@ def test_discriminator_128_matches_reference():
     assert rel_err(out, torch.from_numpy(arr["d_logits_128"])) < 1e-3
 
 
+def test_discriminator_128_backward_fp32_matches_reference():
+    """Config 3's real map sizes (HR 128 x 128: 128, 64, 32, 16, 8 pixels a side,
+    esrgan/discriminator.py:18-25): BCE backward through the drop-in module, fp32 MFMA, against the
+    reference's whole gradient tensors, input gradient and u / v after the pass."""
+    man, arr = golden()
+    case = man["cases"]["d128_bwd"]
+    d = _disc(4, torch.float32)
+    d.train()
+    x = O.hash_input("d.x128", (2, 3, 128, 128)).cuda().requires_grad_(True)
+    out = d(x)
+    assert rel_err(out, torch.from_numpy(arr["d_logits_128"])) < 1e-3
+    loss = torch.nn.BCEWithLogitsLoss()(out, torch.ones_like(out))
+    assert abs(float(loss.detach()) - case["loss_value"]) < 1e-4
+    loss.backward()
+    assert rel_l2(x.grad, torch.from_numpy(arr["d128_gx"])) < 2e-3
+    bad = _grads_close(d, case["grads"], 2e-3)
+    assert not bad, bad[:5]
+    bad = full_grads_bad(((n, p.grad) for n, p in d.named_parameters()), case["full_grads"], arr, 2e-3)
+    assert not bad, bad
+    sd = d.state_dict()
+    for k in ("features.0.0", "features.6.0", "classifier.3"):
+        for s in ("weight_u", "weight_v"):
+            assert rel_err(sd[f"{k}.{s}"], torch.from_numpy(arr[f"d128_after1_{k}.{s}"])) < 1e-4
+
+
+def test_discriminator_128_backward_bf16_kernels_meet_tolerance():
+    """The bf16 gradient kernels of the discriminator chain at 128 x 128 (stride-1 and stride-2
+    data gradients, weight gradients, spectral-norm backward) against the REFERENCE's gradients.
+    As for the generator, the activation-derivative masks are those of an fp32 forward: its saved
+    activations (rounded to bf16, signs unchanged) are placed in the bf16 plan's buffers, so a
+    rounding-level sign flip of a near-zero activation (an O(1) change of one incoherent term at any
+    bf16 forward) does not enter; every whole gradient tensor must then meet 2e-2.  With the masks
+    of its own bf16 forward the direction of the whole gradient is kept (cosine)."""
+    man, arr = golden()
+    case = man["cases"]["d128_bwd"]
+    CH = pkg("chain")
+    D = pkg("esrgan.discriminator")
+    d = fill_module_(D.Discriminator(), salt=4).cuda()
+    params = {n: p.data for n, p in d.named_parameters()}
+    x = O.hash_input("d.x128", (2, 3, 128, 128)).cuda()
+
+    def plan_for(tdtype):
+        bufs = {n: b.clone() for n, b in d.named_buffers()}      # each plan advances its own u, v
+        return CH.DiscriminatorPlan(params, bufs, 2, 128, 128, tdtype, need_param_grad=True, need_input_grad=True)
+
+    p32, p16 = plan_for(torch.float32), plan_for(torch.bfloat16)
+    logits = p32.forward_logits(x, training=True)
+    g = (torch.sigmoid(logits) - 1.0) / logits.numel()            # d BCE(logits, 1) / d logits
+    p32.backward(g)
+    l16 = p16.forward_logits(x, training=True)
+    ref_logits = torch.from_numpy(arr["d_logits_128"])
+    assert float((l16.cpu() - ref_logits).abs().max()) < 2e-2 * max(1.0, float(ref_logits.abs().max()))
+    gx_own = p16.backward(g).clone()
+    own = torch.cat([p16.grads[n].flatten() for n in p16.param_names]).double()
+    for a, b in zip(p16.A, p32.A):
+        a.t.copy_(b.t)
+    gx = p16.backward(g)
+    torch.cuda.synchronize()
+    assert rel_l2(gx, torch.from_numpy(arr["d128_gx"])) < 2e-2
+    bad = full_grads_bad(p16.grads.items(), case["full_grads"], arr, 2e-2)
+    assert not bad, bad
+    ref = torch.cat([p32.grads[n].flatten() for n in p16.param_names]).double()
+    assert float(torch.dot(own, ref) / (own.norm() * ref.norm())) > 0.97
+    assert float(torch.nn.functional.cosine_similarity(gx_own.flatten().double().cpu(),
+                                                       torch.from_numpy(arr["d128_gx"]).flatten().double(), dim=0)) > 0.97
+
+
 def test_state_dict_layout_matches_reference():
     man, _ = golden()
     D = pkg("esrgan.discriminator")
@@ -115,7 +189,9 @@ def test_vgg_features_match_oracle(tdtype):
     assert abs(float(loss.detach()) - float(ref_loss)) / float(ref_loss) < tol
     loss.backward()
     if tdtype == torch.float32:
-        assert rel_l2(ag.grad, a.grad) < 2e-2        # sign()/ReLU flips at rounding level
+        e = rel_l2(ag.grad, a.grad)
+        record_observed("vgg_input_grad_fp32", rel_l2=e)
+        assert e < VGG_GRAD_FP32_TOL                 # sign()/ReLU flips at rounding level
     else:
         cos = torch.nn.functional.cosine_similarity(ag.grad.cpu().flatten(), a.grad.flatten(), dim=0)
         assert float(cos) > 0.9
@@ -161,7 +237,12 @@ def test_adversarial_step_fp32_matches_reference():
     for k, v in (("gen_adv_loss", gen_adv), ("gen_l1_loss", gen_l1), ("gen_vgg_loss", gen_vgg),
                  ("loss_gen", loss_gen)):
         assert abs(float(v.detach()) - case[k]) / abs(case[k]) < 1e-3, k
-    bad = _grads_close(g, case["g_grads"], 1e-2)
+    worst_norm = max(abs(float(p.grad.double().norm()) - case["g_grads"][n]["norm"]) / max(case["g_grads"][n]["norm"], 1e-12)
+                     for n, p in g.named_parameters())
+    worst_l2 = max(rel_l2(dict(g.named_parameters())[n].grad.float().cpu().flatten()[::e["step"]],
+                          torch.from_numpy(arr[e["array"]]).flatten()) for n, e in case["g_full_grads"].items())
+    record_observed("adv_step_g_grads_fp32", worst_norm_err=worst_norm, worst_full_rel_l2=worst_l2)
+    bad = _grads_close(g, case["g_grads"], ADV_G_GRAD_FP32_TOL)
     assert not bad, bad[:5]
-    bad = full_grads_bad(((n, p.grad) for n, p in g.named_parameters()), case["g_full_grads"], arr, 1e-2)
+    bad = full_grads_bad(((n, p.grad) for n, p in g.named_parameters()), case["g_full_grads"], arr, ADV_G_GRAD_FP32_TOL)
     assert not bad, bad

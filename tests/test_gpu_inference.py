@@ -91,3 +91,28 @@ def test_small_image_skips_tiling_and_checkpoint_loads():
     assert rel_err(out, torch.from_numpy(arr["ckpt_g_out"])) < 1e-3
     with pytest.raises(ValueError):
         I.SuperResolutionInference("swinir", model=eng.model)
+
+
+def test_config4_tiling_as_stated_matches_oracle():
+    """BASELINE config 4's tiling (tile 256, overlap 32; inference.py:187-230 defaults) on an image
+    that needs reflect padding and clipped edge tiles: [1,3,300,330], one-block generator, fp32 MFMA,
+    against the oracle's restatement of the tiler run with the oracle generator on the CPU."""
+    eng, sd = _engine(window="hann_pos", tile_batch=4)
+    x = (O.hash_input("inf.c4", (1, 3, 300, 330)) + 1) / 2
+    out = eng.upscale(x, tile_size=256, tile_overlap=32, clamp=False).cpu()
+    ref = O.infer_tiled(x, lambda t: O.generator_forward(t, sd), 256, 32, window="hann_pos")
+    assert out.shape == ref.shape == (1, 3, 1200, 1320)
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_config4_full_size_whole_image_properties():
+    """Config 4's image size (512 x 512 LR -> 2048 x 2048), 23 blocks, bf16, whole image: finite,
+    deterministic, and an image's output does not depend on the batch it is in (config 4 shards
+    32 images over 8 GPUs: replicas only)."""
+    eng, _ = _engine(num_blocks=23, half=True)
+    x = (O.hash_input("inf.c4w", (2, 3, 512, 512)) + 1) / 2
+    y = eng.upscale(x, clamp=False)
+    assert y.shape == (2, 3, 2048, 2048)
+    assert torch.isfinite(y).all() and float(y.abs().max()) > 0
+    assert torch.equal(y, eng.upscale(x, clamp=False))
+    assert torch.equal(eng.upscale(x[1:2], clamp=False), y[1:2])

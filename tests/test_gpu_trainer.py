@@ -7,10 +7,12 @@ import math
 import pytest
 import torch
 
-from helpers import O, fill_module_, full_grads_bad, golden, pkg, rel_err
+from helpers import O, fill_module_, full_grads_bad, golden, pkg, record_observed, rel_err, rel_l2
 from test_gpu_generator import _grads_close
 
 pytestmark = pytest.mark.gpu
+
+NATIVE_G_GRAD_FP32_TOL = 1e-3
 
 
 def _models(num_blocks=2):
@@ -48,9 +50,14 @@ def test_native_adversarial_step_matches_reference_golden():
     assert not bad, bad
     for n, p in g.named_parameters():
         p.grad = tr.gplan.grads[n]
-    bad = _grads_close(g, case["g_grads"], 1e-2)
+    worst_l2 = max(rel_l2(tr.gplan.grads[n].float().cpu().flatten()[::e["step"]], torch.from_numpy(arr[e["array"]]).flatten())
+                   for n, e in case["g_full_grads"].items())
+    record_observed("native_adv_step_g_grads_fp32", worst_full_rel_l2=worst_l2)
+    # (observed on MI355X: 2.2e-6 relative L2, profiles/r3_observed_parity_errors.json; the bar is the
+    #  fp32 tolerance of the whole path)
+    bad = _grads_close(g, case["g_grads"], NATIVE_G_GRAD_FP32_TOL)
     assert not bad, bad[:5]
-    bad = full_grads_bad(tr.gplan.grads.items(), case["g_full_grads"], arr, 1e-2)
+    bad = full_grads_bad(tr.gplan.grads.items(), case["g_full_grads"], arr, NATIVE_G_GRAD_FP32_TOL)
     assert not bad, bad
 
 
@@ -246,3 +253,49 @@ def test_adam_applied_range_by_range_equals_one_launch():
     #  order they arrive, in both runs alike)
     d = (outs[0] - outs[1]).abs()
     assert float(d.mean()) < 1e-6 and float((d > 1e-4).float().mean()) < 1e-3, (float(d.mean()), float(d.max()))
+
+
+def test_config3_full_size_step_properties():
+    """BASELINE config 3 at its stated size (adversarial step, B=16 of 32x32 LR -> HR 128x128, 23
+    blocks, bf16): two trainers built from the same state with deterministic weight gradients run the
+    same step twice and end with the same bits in every generator and discriminator parameter and
+    every spectral-norm buffer; all five losses are finite; and the discriminator's logit of an
+    image does not depend on the batch it sits in (what sharding a batch over GPUs relies on)."""
+    T = pkg("train")
+    E = pkg("engine")
+    CH = pkg("chain")
+    B, h = 16, 32
+    lr = O.hash_input("c3.lr", (B, 3, h, h)).cuda()
+    hr = O.hash_input("c3.hr", (B, 3, 4 * h, 4 * h)).cuda()
+    ends, losses = [], []
+    E.Plan.deterministic_wgrad = True
+    try:
+        for _ in range(2):
+            g, d, vgg = _models(num_blocks=23)
+            tr = T.AdversarialTrainer(g, d, vgg, (B, 3, h, h), torch.bfloat16, lr=2e-4)
+            init = tr.flat_g.clone()
+            tr.step(lr, hr)
+            tr.step(lr, hr)
+            torch.cuda.synchronize()
+            losses.append(tr.losses())
+            ends.append((tr.flat_g.clone(), tr.flat_d.clone(), [b.clone() for b in d.buffers()]))
+            del tr
+    finally:
+        E.Plan.deterministic_wgrad = False
+    for k, v in losses[0].items():
+        assert math.isfinite(v), (k, v)
+        assert abs(v - losses[1][k]) <= 1e-5 * max(1.0, abs(v)), k     # loss sums use atomics: last bits only
+    assert torch.equal(ends[0][0], ends[1][0]), "generator parameters differ between two identical steps"
+    assert torch.equal(ends[0][1], ends[1][1]), "discriminator parameters differ between two identical steps"
+    for a, b in zip(ends[0][2], ends[1][2]):
+        assert torch.equal(a, b)
+    assert float((ends[0][0] - init).abs().max()) > 0
+    # batch independence of the discriminator at HR 128 x 128
+    g, d, vgg = _models(num_blocks=1)
+    params = {n: p.data for n, p in d.named_parameters()}
+    mk = lambda b: CH.DiscriminatorPlan(params, {n: t.clone() for n, t in d.named_buffers()}, b, 4 * h, 4 * h,
+                                        torch.bfloat16, need_param_grad=False, need_input_grad=False)
+    full = mk(B).forward_logits(hr, training=True).clone()
+    part = mk(2).forward_logits(hr[[5, 15]].contiguous(), training=True)
+    assert torch.isfinite(full).all()
+    assert torch.equal(part, full[[5, 15]])
