@@ -435,7 +435,13 @@ def main():
         # the collectives' stream at high priority: its own pool of hardware queues, so it never
         # shares one with the launch chain (normal) or the weight-gradient stream (low)
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        import datetime
+        import faulthandler
+        # a rank that stalls (in the rendezvous, a collective or a device wait) says where and ends,
+        # so that its launcher can stop the other ranks, instead of sitting there until an outer limit
+        faulthandler.dump_traceback_later(max(30.0, args.rank_timeout - 15.0), exit=True)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts,
+                                timeout=datetime.timedelta(seconds=max(30.0, args.rank_timeout - 30.0)))
         assert dist.get_world_size() == world
 
     import ctypes
@@ -580,6 +586,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 

@@ -931,6 +931,9 @@ class GeneratorPlan(_GenBase):
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
         if self.overlap_wgrad:
+            # every stream a step uses exists before the step's first launch, created in one fixed
+            # order (the caller's streams, then this one): never in the middle of a backward pass
+            side_stream(self.device)
             self.bwd_segments, self.bwd_ops, self.bwd_meta, seg_names, self.bwd_seg_meta = \
                 self.split_ops(bwd, side_marks)
             self.bwd_seg_ranges = self._ranges_for(seg_names)

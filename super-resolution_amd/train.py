@@ -320,6 +320,7 @@ class AdversarialTrainer:
         self.steps = 0
         self.B = B
         self._ev_in, self._ev_real, self._ev_y, self._ev_vgg = (torch.cuda.Event() for _ in range(4))
+        engine.side_stream(dev)      # created here, not inside the first step
 
     step_in_backward = False    # as in GeneratorWarmupTrainer
 

@@ -123,3 +123,45 @@ def run_single_conv(x, w, b, *, stride=1, tdtype=torch.float32, act=1.0, alpha=1
     out = plan.c8_to_nchw((Y, 0), cout // 4 if ps else cout)
     torch.cuda.synchronize()
     return out.cpu()
+
+
+def start_stream_watchdog(after_s: float, streams=None, label: str = "", exit_code=None):
+    """A daemon thread that, `after_s` seconds from now, writes to stderr what the HIP runtime reports
+    for every stream of interest — hipStreamQuery per stream (0 = everything queued on it has
+    completed, 600 = not ready) for the null stream, torch's current stream, the library's side
+    stream and any stream in `streams` — plus faulthandler's traceback of every Python thread.
+    A process whose main thread sits in a blocking call (synchronize, a synchronous copy) can thus
+    still say whether the DEVICE never finished the work (a stream reports 600) or the host wait
+    never returned although it did (every stream reports 0).  The query calls do not block.
+    exit_code: if given, the process ends with it after the dump.  Returns a function that
+    cancels the watchdog."""
+    import ctypes as C
+    import faulthandler
+    import threading
+    cancelled = threading.Event()
+
+    def run():
+        if cancelled.wait(after_s):
+            return
+        rep = {"watchdog": label, "after_s": after_s}
+        try:
+            hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            q = lambda ptr: int(hip.hipStreamQuery(C.c_void_p(ptr)))
+            rep["null_stream"] = q(0)
+            named = dict(streams or {})
+            E = sys.modules.get(PKG + ".engine")
+            if E is not None:
+                for idx, st in getattr(E, "_SIDE_STREAMS", {}).items():
+                    named["side_stream_dev%d" % idx] = st
+            for k, st in named.items():
+                rep[k] = q(st.cuda_stream)
+        except Exception as e:                     # the dump must not raise out of the thread
+            rep["error"] = repr(e)
+        sys.stderr.write("STREAM-WATCHDOG " + json.dumps(rep) + "\n")
+        sys.stderr.flush()
+        faulthandler.dump_traceback(all_threads=True)
+        if exit_code is not None:
+            os._exit(exit_code)
+
+    threading.Thread(target=run, daemon=True).start()
+    return cancelled.set

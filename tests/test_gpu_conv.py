@@ -1,4 +1,6 @@
 """GPU parity of the HIP convolution (C ABI srx_conv2d) against the CPU oracle."""
+import os
+
 import pytest
 import torch
 
@@ -155,27 +157,55 @@ def test_eight_wave_workgroup_shape_matches(tmp_path):
 
 
 def test_stream_create_priorities_and_side_stream():
-    """srx_stream_create: a low- and a normal-priority stream run the same convolution to the same
-    bits; a priority outside the device's range is an argument error; engine.side_stream hands out
-    one low-priority stream per device.  (The library itself only ever creates the one
-    low-priority stream.  A high-priority stream created here as a process's fifth stream, after a
-    backward pass had used the side stream, was seen never to start its work on this runtime, so
-    the test keeps to what the product does.)"""
+    """srx_stream_create: streams of low, normal and HIGH priority, each created late in the process's
+    life (after other tests have run backward passes on the low-priority side stream), run the same
+    convolution to the same bits as the main stream; a priority outside the device's range is an
+    argument error; engine.side_stream hands out one stream per device.
+    The streams get what the product gives a side stream: recorded launches behind an event of the
+    main stream, nothing synchronous.  Completion is polled for a bounded time, and a stream that
+    does not finish fails the test with every stream's hipStreamQuery state instead of blocking."""
     import ctypes as C
+    import time
     E, L = pkg("engine"), pkg("_lib")
     lib = L.lib()
-    x = O.hash_input("xs", (2, 64, 16, 32))
-    w = O.hash_uniform("ws", (32, 64, 3, 3), 0.05)
-    b = O.hash_uniform("bs", (32,), 0.1)
+    dev = torch.device("cuda")
+    x = O.hash_input("xs", (2, 64, 16, 32)).cuda()
+    w = O.hash_uniform("ws", (32, 64, 3, 3), 0.05).cuda()
+    b = O.hash_uniform("bs", (32,), 0.1).cuda()
     base = run_single_conv(x, w, b, tdtype=torch.bfloat16, act=0.2)
-    for prio in (1, 0):
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    for prio in (1, 0, -1):
+        # buffers, packed weights and the converted input on the main stream ...
+        plan = E.Plan(dev, torch.bfloat16)
+        X, Y = plan.buf(2, 64, 16, 32), plan.buf(2, 32, 16, 32, zero=True)
+        wp, bp = plan.packed_layer(32, 64, 9, 0, [E.conv_seg(w)], b.data_ptr())
+        plan.finalize_packing()
+        plan.run_packing()
+        plan.nchw_to_c8(x, (X, 0))
+        ops = []
+        plan.conv(ops, (X, 0), (Y, 0), wp, bp, 2, 16, 32, 64, 32, act=0.2)
+        frozen = plan.freeze(ops)
+        # ... the launch on a new stream of the given priority, behind an event of the main stream
         sp = C.c_void_p()
         assert lib.srx_stream_create(prio, C.byref(sp)) == 0 and sp.value
+        got = C.c_int(99)
+        assert hip.hipStreamGetPriority(sp, C.byref(got)) == 0 and got.value == prio
         st = torch.cuda.ExternalStream(sp.value)
         st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            out = run_single_conv(x, w, b, tdtype=torch.bfloat16, act=0.2)
-        st.synchronize()
+        plan.run(frozen, stream=st)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        t0 = time.monotonic()
+        while not ev.query() and time.monotonic() - t0 < 20.0:
+            time.sleep(0.005)
+        if not ev.query():
+            q = lambda p: int(hip.hipStreamQuery(C.c_void_p(p)))
+            pytest.fail("the convolution launched on a stream of priority %d did not finish in 20 s; hipStreamQuery "
+                        "(0 = done, 600 = not ready): new stream %d, main stream %d, null stream %d, side stream %d"
+                        % (prio, q(sp.value), q(torch.cuda.current_stream().cuda_stream), q(0),
+                           q(E.side_stream(dev).cuda_stream)))
+        torch.cuda.current_stream().wait_stream(st)
+        out = plan.c8_to_nchw((Y, 0), 32).cpu()
         assert torch.equal(out, base)
         assert lib.srx_stream_destroy(sp) == 0
     sp = C.c_void_p()
