@@ -432,9 +432,13 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-        # the collectives' stream at high priority: its own pool of hardware queues, so it never
-        # shares one with the launch chain (normal) or the weight-gradient stream (low)
-        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        # Every stream of a step has the SAME (normal) priority: on this runtime a stream that waits
+        # for an event of a lower-priority stream can keep that stream from ever being scheduled
+        # (tools/stream_priority_probe.py).  The runtime gives each of the first four streams of a
+        # priority a hardware queue of its own, so the weight-gradient stream is created before the
+        # process group's: launch chain, weight gradients and collectives then never share a queue.
+        importlib.import_module("super-resolution_amd.engine").side_stream(dev)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("SRX_PG_HIGH_PRIORITY") == "1")
         import datetime
         import faulthandler
         # a rank that stalls (in the rendezvous, a collective or a device wait) says where and ends,

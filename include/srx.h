@@ -366,11 +366,14 @@ typedef struct srx_op {
  * crossing of the language boundary (a whole generator forward or backward). */
 int srx_run_ops(const srx_op* ops, int n, void* stream);
 /* A non-blocking stream of the given HIP priority (1 low, 0 normal, -1 high) on the current
- * device, for the weight-gradient launches that run beside the data-gradient chain.  The runtime
- * keeps one pool of hardware queues per priority (four queues each by default): a side stream of
- * NORMAL priority created after a few others (a process group's, a data loader's) can land on
- * the caller's own hardware queue, and the two launch chains then run one after the other
- * instead of side by side; a stream of another priority never shares a queue with it.
+ * device, for launches that run beside the caller's chain (weight gradients beside data gradients).
+ * The runtime keeps one pool of hardware queues per priority (four each by default) and gives a new
+ * stream a queue of its own while its pool has room; later streams share queues, and two launch
+ * chains on one queue run one after the other.
+ * HAZARD (observed on gfx950 / ROCm 7.2): a stream that waits on the device for an event of a
+ * LOWER-priority stream (hipStreamWaitEvent) can keep that stream from being scheduled, and then
+ * neither finishes.  Let streams that wait for each other have the same priority, or join them on
+ * the host.  The library's own side stream has normal priority for that reason.
  * No counterpart in the reference (single stream, esrgan/train_esrgan.py:80-118). */
 int srx_stream_create(int priority, void** stream);
 int srx_stream_destroy(void* stream);

@@ -53,16 +53,21 @@ _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 def side_stream(device) -> "torch.cuda.Stream":
     """The device's stream for work that runs BESIDE the current stream's launch chain (weight
-    gradients next to data gradients).  Low HIP priority, created through the library: streams of
-    one priority share a small pool of hardware queues, and a normal-priority side stream made
-    after a process group's streams was measured to land on the main chain's own queue — both
-    chains then alternate instead of overlapping (13.2 instead of 11.1 ms per step).  A low-priority
-    stream draws from another pool, and leaves dispatch precedence to the critical chain."""
+    gradients next to data gradients, packing under the forward pass).  NORMAL priority, like the
+    caller's stream: on this runtime a stream that waits for an event of a LOWER-priority stream can
+    keep that stream from ever being scheduled (observed: a high-priority stream waiting for the
+    main stream, and the main stream waiting for a low-priority side stream while other processes
+    share the card; tools/stream_priority_probe.py), and a step's streams wait for each other in
+    both directions.  With equal priorities the hardware scheduler time-slices and every wait ends.
+    The runtime gives each of the first four streams of a priority its own hardware queue, so this
+    stream is created when the first plan or trainer is built (before a process group's streams):
+    a side stream that shares the main chain's queue runs after it instead of beside it (13.2
+    instead of 11.1 ms per step).  Created through the library (srx_stream_create)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     st = _SIDE_STREAMS.get(idx)
     if st is None:
-        prio = int(os.environ.get("SRX_SIDE_STREAM_PRIORITY", "1"))
+        prio = int(os.environ.get("SRX_SIDE_STREAM_PRIORITY", "0"))     # A/B runs only
         out = C.c_void_p()
         with torch.cuda.device(idx):
             L.check(L.lib().srx_stream_create(prio, C.byref(out)), "srx_stream_create")

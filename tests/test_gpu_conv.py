@@ -161,9 +161,12 @@ def test_stream_create_priorities_and_side_stream():
     life (after other tests have run backward passes on the low-priority side stream), run the same
     convolution to the same bits as the main stream; a priority outside the device's range is an
     argument error; engine.side_stream hands out one stream per device.
-    The streams get what the product gives a side stream: recorded launches behind an event of the
-    main stream, nothing synchronous.  Completion is polled for a bounded time, and a stream that
-    does not finish fails the test with every stream's hipStreamQuery state instead of blocking."""
+    The new stream's launch is ordered after the main stream's set-up work by a HOST-side join: a
+    device-side wait of a higher-priority stream for an event of a lower-priority one is the one
+    pattern this runtime does not survive (with st.wait_stream(main) the priority -1 case left
+    both the new stream and the main stream unfinished: hipStreamQuery 600 / 600, side stream 0).
+    Completion is polled for a bounded time, and a stream that does not finish fails the test with
+    every stream's hipStreamQuery state instead of blocking."""
     import ctypes as C
     import time
     E, L = pkg("engine"), pkg("_lib")
@@ -185,13 +188,13 @@ def test_stream_create_priorities_and_side_stream():
         ops = []
         plan.conv(ops, (X, 0), (Y, 0), wp, bp, 2, 16, 32, 64, 32, act=0.2)
         frozen = plan.freeze(ops)
-        # ... the launch on a new stream of the given priority, behind an event of the main stream
+        # ... the launch on a new stream of the given priority, after a host-side join
         sp = C.c_void_p()
         assert lib.srx_stream_create(prio, C.byref(sp)) == 0 and sp.value
         got = C.c_int(99)
         assert hip.hipStreamGetPriority(sp, C.byref(got)) == 0 and got.value == prio
         st = torch.cuda.ExternalStream(sp.value)
-        st.wait_stream(torch.cuda.current_stream())
+        torch.cuda.current_stream().synchronize()
         plan.run(frozen, stream=st)
         ev = torch.cuda.Event()
         ev.record(st)
@@ -204,8 +207,7 @@ def test_stream_create_priorities_and_side_stream():
                         "(0 = done, 600 = not ready): new stream %d, main stream %d, null stream %d, side stream %d"
                         % (prio, q(sp.value), q(torch.cuda.current_stream().cuda_stream), q(0),
                            q(E.side_stream(dev).cuda_stream)))
-        torch.cuda.current_stream().wait_stream(st)
-        out = plan.c8_to_nchw((Y, 0), 32).cpu()
+        out = plan.c8_to_nchw((Y, 0), 32).cpu()       # (the event has completed: a host-side join)
         assert torch.equal(out, base)
         assert lib.srx_stream_destroy(sp) == 0
     sp = C.c_void_p()
