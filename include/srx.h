@@ -264,7 +264,11 @@ int srx_sn_power_iter(const srx_sn_layer* layers /*DEVICE*/, int n, int do_power
  * Limit: n * max_rows <= srx_sn_scratch_floats() (65536 floats = 256 KB per GPU, held until the
  * process ends); larger problems are rejected with SRX_ERR_INVALID.  Calls no hipMalloc / hipFree
  * or any allocating routine.  Every call on a GPU shares that GPU's array: calls that overlap on
- * one GPU (two streams, two threads) race; serialise them or use srx_sn_power_iter. */
+ * one GPU (two streams, two threads) race; serialise them or use srx_sn_power_iter.
+ * Set-up: the array's device address is looked up once per device (hipGetSymbolAddress, which may
+ * load the library's code object).  srx_sn_scratch_floats() does that for the current device: call
+ * it once per device before the first call that must not touch the runtime (e.g. before a stream
+ * capture begins); otherwise the first srx_sn_power_iter_noalloc call on a device does it. */
 int srx_sn_power_iter_noalloc(const srx_sn_layer* layers /*DEVICE*/, int n, int do_power_iteration,
                               int max_rows, int max_cols, void* stream);
 int srx_sn_scratch_floats(void);
@@ -275,7 +279,10 @@ typedef struct srx_sn_bwd_layer {
   float* dot; /* scratch [1] */
   int32_t rows, cols;
 } srx_sn_bwd_layer;
-int srx_sn_backward(const srx_sn_bwd_layer* layers /*DEVICE*/, int n, int max_elems, void* stream);
+/* deterministic != 0: each layer's <dW_sn, W_orig> is summed by one workgroup in a fixed order
+ * (same inputs, same bits) instead of by atomic adds; the update itself is elementwise either way. */
+int srx_sn_backward(const srx_sn_bwd_layer* layers /*DEVICE*/, int n, int max_elems, int deterministic,
+                    void* stream);
 /* Same as srx_pack_weights but every segment's scale is multiplied by
  * *scale_ptr[i] (device floats, e.g. inv_sigma) when scale_ptr[i] != NULL. */
 int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs,

@@ -131,7 +131,7 @@ _SIGS = {
     "srx_sn_power_iter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "srx_sn_power_iter_noalloc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "srx_sn_scratch_floats": (C.c_int, []),
-    "srx_sn_backward": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "srx_sn_backward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "srx_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
     "srx_run_ops": (C.c_int, [vp, C.c_int, vp]),
     "srx_stream_create": (C.c_int, [C.c_int, C.POINTER(vp)]),

@@ -176,6 +176,7 @@ class ChainPlan(Plan, _GradMixin):
                     if produce_input:
                         self.generic(bwd, L.OP_GAP_BWD, a=(self.gA[i], 0), c=(self.gA[i - 1], 0), mask=dst_mask,
                                      f0=dst_slope, B=b_i, H=h_i, W=w_i, noct=_ceil(c_i, 8))
+            self.trim_stage_memset(bwd)
             self.bwd_ops, self.bwd_meta = self.freeze(bwd), bwd.meta
         self.finalize_packing()
         self.finalize_unpack()
@@ -298,10 +299,8 @@ class DiscriminatorPlan(ChainPlan):
     def backward_c8(self) -> None:
         super().backward_c8()
         if self.need_param_grad:
-            # (a launch sized for one element per layer sums <dW, W> in one workgroup, in a fixed
-            #  order: the deterministic form)
-            L.check(self.lib.srx_sn_backward(self._snb_dev.data_ptr(), self.nl,
-                                             1 if self.deterministic_wgrad else self.unpack_max,
+            L.check(self.lib.srx_sn_backward(self._snb_dev.data_ptr(), self.nl, self.unpack_max,
+                                             1 if self.deterministic_wgrad else 0,
                                              stream_ptr(self.device)), "srx_sn_backward")
 
     def input_grad(self) -> torch.Tensor:

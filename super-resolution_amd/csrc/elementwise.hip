@@ -861,7 +861,14 @@ int srx_sn_power_iter(const srx_sn_layer* layers, int n, int do_pi, int max_rows
   return sn_power_iter_launch(layers, n, do_pi, max_rows, max_cols, nullptr, 0, stream);
 }
 
-int srx_sn_scratch_floats(void) { return SN_SCRATCH_FLOATS; }
+int srx_sn_scratch_floats(void) {
+  // also the set-up call of srx_sn_power_iter_noalloc: resolves the static array's address on the
+  // current device (hipGetSymbolAddress may load the code object: not something to do for the first
+  // time inside a stream capture).  Without a device it only reports the size.
+  float* ptr = nullptr;
+  (void)sn_scratch_ptr(&ptr);
+  return SN_SCRATCH_FLOATS;
+}
 
 int srx_sn_power_iter_noalloc(const srx_sn_layer* layers, int n, int do_pi, int max_rows, int max_cols,
                               void* stream) {
@@ -877,11 +884,13 @@ int srx_sn_power_iter_noalloc(const srx_sn_layer* layers, int n, int do_pi, int 
   return sn_power_iter_launch(layers, n, do_pi, max_rows, max_cols, ptr, max_rows, stream);
 }
 
-int srx_sn_backward(const srx_sn_bwd_layer* layers, int n, int max_elems, void* stream) {
+int srx_sn_backward(const srx_sn_bwd_layer* layers, int n, int max_elems, int deterministic, void* stream) {
   SRX_CHECK_ARG(layers && n > 0 && max_elems > 0, "srx_sn_backward: bad argument");
   hipLaunchKernelGGL(sn_bwd_zero_kernel, dim3(1), dim3(TPB), 0, STREAM, layers, n);
   dim3 grid(grid_for(max_elems, TPB * 4, 512), n);
-  hipLaunchKernelGGL(sn_bwd_dot_kernel, grid, dim3(TPB), 0, STREAM, layers);
+  // deterministic: <dW, W> of a layer summed by ONE workgroup (a fixed order instead of atomic adds
+  // from many); the elementwise update that follows has no order to keep and always takes the full grid
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, deterministic ? dim3(1, n) : grid, dim3(TPB), 0, STREAM, layers);
   hipLaunchKernelGGL(sn_bwd_apply_kernel, grid, dim3(TPB), 0, STREAM, layers);
   return srx_check_launch("sn_backward");
 }

@@ -450,6 +450,17 @@ class Plan:
         self.unpack_items.append(it)
         self.unpack_max = max(self.unpack_max, cout * cin * taps)
 
+    def trim_stage_memset(self, ops: list) -> None:
+        """Deterministic form: the staging buffer holds det_slices copies of the gradient tensors, of
+        which the launches of this plan use only the first max(nslices); the recorded memset of the
+        buffer (ops built so far, not yet frozen) is cut to those copies."""
+        if not (self.deterministic_wgrad and self._stage_total > 0):
+            return
+        used = max([it.nslices for it in self.unpack_items] + [1])
+        for op in ops:
+            if op.kind == L.OP_MEMSET and op.u.g.c == self.stage.data_ptr():
+                op.u.g.n = min(op.u.g.n, used * self._stage_total * 4)
+
     def finalize_unpack(self):
         if self.unpack_items:
             arr = (L.UnpackItem * len(self.unpack_items))(*self.unpack_items)
@@ -935,6 +946,7 @@ class GeneratorPlan(_GenBase):
         if self.need_input_grad:
             self.conv(bwd, (self.gfeat, 0), (self.gX0, 0), self.dgrad_layer(P, "conv_first", in_ch), 0,
                       B, h, w, nf, in_ch)
+        self.trim_stage_memset(bwd)
         if self.overlap_wgrad:
             # every stream a step uses exists before the step's first launch, created in one fixed
             # order (the caller's streams, then this one): never in the middle of a backward pass
@@ -1041,6 +1053,7 @@ class BlockPlan(_GenBase):
         else:
             raise ValueError(kind)
         self.fwd_ops = self.freeze(fwd)
+        self.trim_stage_memset(bwd)
         self.bwd_ops = self.freeze(bwd) if need_grad else None
         self.finalize_packing()
         self.finalize_unpack()

@@ -28,7 +28,7 @@ def _problem(shapes, salt):
     return ws, us, vs
 
 
-def _run(entry, shapes, salt, do_pi, give_wv):
+def _run(entry, shapes, salt, do_pi, give_wv, stream=None):
     L = pkg("_lib")
     lib = L.lib()
     dev = torch.device("cuda")
@@ -44,8 +44,10 @@ def _run(entry, shapes, salt, do_pi, give_wv):
         a.wv = wv[i].data_ptr() if give_wv else None
         a.rows, a.cols = s
     table = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), C.sizeof(arr))), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()          # the table and the operands are in place before another stream reads them
+    st = stream if stream is not None else torch.cuda.current_stream()
     rc = getattr(lib, entry)(table.data_ptr(), n, do_pi, max(s[0] for s in shapes), max(s[1] for s in shapes),
-                             torch.cuda.current_stream().cuda_stream)
+                             st.cuda_stream)
     assert rc == 0, lib.srx_last_error()
     torch.cuda.synchronize()
     return [u.cpu() for u in us], [v.cpu() for v in vs], inv_sigma.cpu()
@@ -62,9 +64,12 @@ def _same(a, b):
 def test_noalloc_power_iteration_equals_the_allocating_entry_point():
     L = pkg("_lib")
     lib = L.lib()
+    # the set-up call: size of the static array; also resolves its address on this device, so that
+    # the calls below (the first of them on a stream of its own) find it ready
     assert lib.srx_sn_scratch_floats() == 65536
-    # first call: the discriminator's layers, training mode (power iteration) ...
-    _same(_run("srx_sn_power_iter_noalloc", BIG, 1, 1, False), _run("srx_sn_power_iter", BIG, 1, 1, True))
+    # first call: the discriminator's layers, training mode (power iteration), on a non-default stream ...
+    _same(_run("srx_sn_power_iter_noalloc", BIG, 1, 1, False, stream=torch.cuda.Stream()),
+          _run("srx_sn_power_iter", BIG, 1, 1, True))
     # ... second call, smaller problem: whatever the first left in the static array must not matter
     _same(_run("srx_sn_power_iter_noalloc", SMALL, 2, 1, False), _run("srx_sn_power_iter", SMALL, 2, 1, True))
     # eval mode (sigma from the stored u, v; no update)
