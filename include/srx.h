@@ -289,6 +289,15 @@ int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_p
                             const float* const* seg_scale_ptr /*DEVICE, per segment*/,
                             int nlayers, int64_t max_elems, void* stream);
 
+/* The same packing driven by a flat DEVICE table with one entry per (layer, unit) pair,
+ * entry = layer index << 16 | unit index, unit = block * nchunk + chunk of that layer
+ * (0 <= unit < nblk * nchunk; at most 65535 layers and 65536 units per layer): every workgroup
+ * that starts has work, which is what a table of many small layers (the generator's 701) needs.
+ * The layer indices are relative to `layers`; seg_scale_ptr may be NULL. */
+int srx_pack_weights_flat(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs,
+                          const float* const* seg_scale_ptr /*DEVICE, per segment*/,
+                          const uint32_t* unit_table /*DEVICE*/, int total_units, void* stream);
+
 /* --------------------------------------------------------------- optimizer */
 /* torch.optim.Adam step (esrgan/train_esrgan.py:134-135,97,110) over a flat
  * fp32 parameter range: p,g,m,v of n elements; bias corrections from step. */

@@ -109,6 +109,7 @@ _SIGS = {
     "srx_c8_to_nchw": (C.c_int, [C.c_int, vp, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "srx_pack_weights": (C.c_int, [C.c_int, vp, vp, C.c_int, i64, vp]),
     "srx_pack_weights_scaled": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, i64, vp]),
+    "srx_pack_weights_flat": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "srx_conv2d": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "srx_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
     "srx_unpack_wgrad": (C.c_int, [vp, C.c_int, i64, vp]),

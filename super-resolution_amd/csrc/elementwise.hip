@@ -78,8 +78,9 @@ constexpr int PACK_MAX_SEGS = 8;     // segments of a layer cached in LDS (a den
 template <typename T, int taps>      // taps is a compile-time constant: the index arithmetic is all divisions by it
 __device__ __forceinline__ void pack_units(const srx_pack_layer& L, const srx_pack_seg* __restrict__ segs,
                                            const float* const* __restrict__ seg_scale_ptr, float* tile,
-                                           srx_pack_seg* ssegs, PackCol* cols) {
-  const int nunits = L.nblk * L.nchunk;
+                                           srx_pack_seg* ssegs, PackCol* cols, int u_begin, int u_step,
+                                           int u_end) {
+  const int nunits = u_end < L.nblk * L.nchunk ? u_end : L.nblk * L.nchunk;
   static_assert(512 % TPB == 0, "pairs per thread");
   T* dst = reinterpret_cast<T*>(L.dst_w);
   // the layer's segments, with the run-time scale folded in, next to the tile
@@ -91,7 +92,7 @@ __device__ __forceinline__ void pack_units(const srx_pack_layer& L, const srx_pa
   }
   __syncthreads();
   const bool tr = nseg > 0 && ssegs[0].transposed != 0;   // read order only
-  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+  for (int u = u_begin; u < nunits; u += u_step) {
     const int nb = u / L.nchunk, chunk = u - nb * L.nchunk;
     // per input channel of the chunk (16 of them): where its source run starts for output channel 0,
     // the step per output channel, the scale, and whether the taps are flipped — one segment
@@ -145,6 +146,15 @@ __device__ __forceinline__ void pack_units(const srx_pack_layer& L, const srx_pa
   }
 }
 
+__device__ __forceinline__ void pack_bias(const srx_pack_layer& L) {
+  for (int i = threadIdx.x; i < L.nblk * 32; i += blockDim.x) {
+    int nb = i >> 5, hh = (i >> 4) & 1, reg = i & 15;
+    int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+    int n = nb * 32 + srx_row_to_chan(row, L.perm);
+    L.dst_bias[i] = (L.src_bias && n < L.cout) ? L.src_bias[n] : 0.f;
+  }
+}
+
 // grid = (units, ceil(nlayers / PACK_LPB)): a workgroup serves its unit index in PACK_LPB consecutive
 // layers.  Most layers have far fewer units than the largest one, and a launch of (max units x
 // layers) workgroups that exit at once is bound by the dispatcher (45 000 workgroups: 150 us).
@@ -159,17 +169,34 @@ __global__ void pack_kernel(const srx_pack_layer* __restrict__ layers,
   for (int li = blockIdx.y * PACK_LPB; li < nlayers && li < (int)(blockIdx.y + 1) * PACK_LPB; ++li) {
     const srx_pack_layer L = layers[li];
     if ((int)blockIdx.x < L.nblk * L.nchunk) {
-      if (L.taps == 9) pack_units<T, 9>(L, segs, seg_scale_ptr, tile, ssegs, cols);
-      else if (L.taps == 1) pack_units<T, 1>(L, segs, seg_scale_ptr, tile, ssegs, cols);
+      if (L.taps == 9) pack_units<T, 9>(L, segs, seg_scale_ptr, tile, ssegs, cols, blockIdx.x, gridDim.x, 1 << 30);
+      else if (L.taps == 1) pack_units<T, 1>(L, segs, seg_scale_ptr, tile, ssegs, cols, blockIdx.x, gridDim.x, 1 << 30);
     }
-    if (blockIdx.x == 0 && L.dst_bias) {
-      for (int i = threadIdx.x; i < L.nblk * 32; i += blockDim.x) {
-        int nb = i >> 5, hh = (i >> 4) & 1, reg = i & 15;
-        int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        int n = nb * 32 + srx_row_to_chan(row, L.perm);
-        L.dst_bias[i] = (L.src_bias && n < L.cout) ? L.src_bias[n] : 0.f;
-      }
-    }
+    if (blockIdx.x == 0 && L.dst_bias) pack_bias(L);
+  }
+}
+
+// The same packing driven by a flat table of (layer, unit) pairs, one entry per unit of every layer
+// (layer << 16 | unit): a grid of a few workgroups per CU walks the table.  The two-dimensional
+// grid above launches (largest layer's units, capped) x layers workgroups, two thirds of which
+// find nothing to do for a generator's 701 layers, and is bound by the rate at which workgroups
+// are dispatched; here every workgroup that starts has work.
+template <typename T>
+__global__ void pack_flat_kernel(const srx_pack_layer* __restrict__ layers,
+                                 const srx_pack_seg* __restrict__ segs,
+                                 const float* const* __restrict__ seg_scale_ptr,
+                                 const unsigned* __restrict__ unit_table, int total_units) {
+  __shared__ __attribute__((aligned(16))) float tile[9 * PACK_PLANE];
+  __shared__ srx_pack_seg ssegs[PACK_MAX_SEGS];
+  __shared__ PackCol cols[16];
+  for (int gu = blockIdx.x; gu < total_units; gu += gridDim.x) {
+    const unsigned ent = unit_table[gu];
+    const srx_pack_layer L = layers[ent >> 16];
+    const int u = (int)(ent & 0xffffu);
+    if (L.taps == 9) pack_units<T, 9>(L, segs, seg_scale_ptr, tile, ssegs, cols, u, 1, u + 1);
+    else if (L.taps == 1) pack_units<T, 1>(L, segs, seg_scale_ptr, tile, ssegs, cols, u, 1, u + 1);
+    if (u == 0 && L.dst_bias) pack_bias(L);
+    __syncthreads();                 // ssegs / cols / tile are rewritten by the next unit
   }
 }
 
@@ -696,6 +723,17 @@ int srx_pack_weights_scaled(int dtype, const srx_pack_layer* layers, const srx_p
              hipLaunchKernelGGL(pack_kernel<bf16>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, nlayers),
              hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, nlayers));
   return srx_check_launch("pack_kernel");
+}
+
+int srx_pack_weights_flat(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs,
+                          const float* const* seg_scale_ptr, const uint32_t* unit_table, int total_units,
+                          void* stream) {
+  SRX_CHECK_ARG(layers && segs && unit_table && total_units > 0, "srx_pack_weights_flat: bad argument");
+  dim3 grid(grid_for(total_units, 1, 1L << 20));      // one workgroup per unit: the units hide each other's load latency
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_flat_kernel<bf16>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, unit_table, total_units),
+             hipLaunchKernelGGL(pack_flat_kernel<float>, grid, dim3(TPB), 0, STREAM, layers, segs, seg_scale_ptr, unit_table, total_units));
+  return srx_check_launch("pack_flat_kernel");
 }
 
 int srx_pack_weights(int dtype, const srx_pack_layer* layers, const srx_pack_seg* segs, int nlayers,

@@ -141,6 +141,7 @@ class Plan:
         self._item_by_src = {}
         self.keep: List[torch.Tensor] = []
         self.pack_layers: List[L.PackLayer] = []
+        self.packed_tensors: List[Tuple[torch.Tensor, Optional[torch.Tensor]]] = []   # (weights, bias) per layer
         self.pack_segs: List[L.PackSeg] = []
         self.pack_scale_ptrs: List[int] = []
         self.pack_max_elems = 0
@@ -182,6 +183,7 @@ class Plan:
         bias = None
         if with_bias:
             bias = self.f32(nblk * 32)
+        self.packed_tensors.append((w, bias))
         lay = L.PackLayer()
         lay.dst_w = w.data_ptr()
         lay.dst_bias = bias.data_ptr() if bias is not None else None
@@ -202,6 +204,9 @@ class Plan:
         self.pack_max_elems = max(self.pack_max_elems, nel)
         return w.data_ptr(), (bias.data_ptr() if bias is not None else 0)
 
+    # False (SRX_FLAT_PACK=0): the (units x layers) grid of srx_pack_weights_scaled (A/B runs, tests)
+    flat_packing = os.environ.get("SRX_FLAT_PACK", "1") != "0"
+
     def finalize_packing(self):
         if not self.pack_layers:
             return
@@ -210,6 +215,16 @@ class Plan:
         pa = (C.c_void_p * len(self.pack_scale_ptrs))(*[p or None for p in self.pack_scale_ptrs])
         self._pack_dev = (self.upload(la), self.upload(sa), self.upload(pa))
         self._pack_scaled = any(self.pack_scale_ptrs)
+        # flat (layer, unit) table for srx_pack_weights_flat, and where each layer's units start in it
+        starts, ents = [], []
+        for li, lay in enumerate(self.pack_layers):
+            starts.append(len(ents))
+            n_units = lay.nblk * lay.nchunk
+            assert li < 65536 and n_units <= 65536
+            ents += [(li << 16) | u for u in range(n_units)]
+        starts.append(len(ents))
+        self._pack_unit_start = starts
+        self._pack_units_dev = self.upload((C.c_uint32 * max(1, len(ents)))(*ents))
 
     def run_packing(self, first: int = 0, count: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
         """Pack layers [first, first+count) of the table (default: all) on `stream` (default: current)."""
@@ -220,9 +235,15 @@ class Plan:
             return
         la, sa, pa = self._pack_dev
         sp = stream.cuda_stream if stream is not None else stream_ptr(self.device)
-        rc = self.lib.srx_pack_weights_scaled(self.dt, la.data_ptr() + first * C.sizeof(L.PackLayer), sa.data_ptr(),
-                                              pa.data_ptr() if self._pack_scaled else None,
-                                              count, self.pack_max_elems, sp)
+        u0, u1 = self._pack_unit_start[first], self._pack_unit_start[first + count]
+        if self.flat_packing and u1 > u0:
+            rc = self.lib.srx_pack_weights_flat(self.dt, la.data_ptr(), sa.data_ptr(),
+                                                pa.data_ptr() if self._pack_scaled else None,
+                                                self._pack_units_dev.data_ptr() + 4 * u0, u1 - u0, sp)
+        else:
+            rc = self.lib.srx_pack_weights_scaled(self.dt, la.data_ptr() + first * C.sizeof(L.PackLayer), sa.data_ptr(),
+                                                  pa.data_ptr() if self._pack_scaled else None,
+                                                  count, self.pack_max_elems, sp)
         L.check(rc, "srx_pack_weights")
 
     # --------------------------------------------------------------- ops

@@ -215,3 +215,40 @@ def test_stream_create_priorities_and_side_stream():
     assert b"priority" in lib.srx_last_error()
     s1, s2 = E.side_stream(torch.device("cuda")), E.side_stream(torch.device("cuda", 0))
     assert s1 is s2
+
+
+def test_flat_table_packing_equals_grid_packing():
+    """srx_pack_weights_flat (one workgroup pass per (layer, unit) table entry) writes the same bits
+    as srx_pack_weights_scaled (units x layers grid) for every packed tensor of a generator plan
+    (forward layers, PixelShuffle row order, the stacked / transposed / tap-flipped data-gradient
+    layers), of a discriminator plan (1/sigma scales read from the device, 1x1 layers) and for a
+    sub-range of the layer table."""
+    E, CH = pkg("engine"), pkg("chain")
+    G, D = pkg("esrgan.generator"), pkg("esrgan.discriminator")
+    from helpers import fill_module_
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=2), salt=41).cuda()
+    d = fill_module_(D.Discriminator(), salt=42).cuda()
+    gp = E.GeneratorPlan({n: p.data for n, p in g.named_parameters()}, 1, 16, 16, torch.bfloat16, num_blocks=2)
+    dp = CH.DiscriminatorPlan({n: p.data for n, p in d.named_parameters()}, {n: b for n, b in d.named_buffers()},
+                              1, 32, 32, torch.float32)
+    dp.inv_sigma.copy_(torch.linspace(0.5, 1.5, dp.inv_sigma.numel()))
+
+    def packed(plan, flat, first=0, count=None):
+        for w, b in plan.packed_tensors:
+            w.fill_(7.0)
+            if b is not None:
+                b.fill_(7.0)
+        plan.flat_packing = flat
+        plan.run_packing(first, count)
+        torch.cuda.synchronize()
+        return [(w.clone(), None if b is None else b.clone()) for w, b in plan.packed_tensors]
+
+    for plan in (gp, dp):
+        for first, count in ((0, None), (3, 5)):
+            a, b = packed(plan, False, first, count), packed(plan, True, first, count)
+            assert len(a) == len(plan.pack_layers) > 5
+            for (wa, ba), (wb, bb) in zip(a, b):
+                assert torch.equal(wa.view(torch.int16 if wa.dtype == torch.bfloat16 else torch.int32),
+                                   wb.view(torch.int16 if wb.dtype == torch.bfloat16 else torch.int32))
+                assert (ba is None) == (bb is None) and (ba is None or torch.equal(ba, bb))
+        assert any(float(w.float().abs().max()) not in (0.0, 7.0) for w, _ in a)

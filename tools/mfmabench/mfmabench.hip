@@ -1,5 +1,11 @@
 // Bare MFMA loops, one wave per SIMD on every CU: v_mfma_f32_32x32x16_bf16 against
-// v_mfma_f32_16x16x32_bf16 on random operands — FLOP/s and the clock the chip holds.
+// v_mfma_f32_16x16x32_bf16 on random operands — FLOP/s, cycles per instruction and the clock the chip holds.
+// Build:  hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form mfmabench.hip -o mfmabench
+// The flag matters: without it hipcc keeps the eight 4-register accumulators of the 16x16x32 loop in
+// AGPRs and rotates them through VGPRs every iteration (about sixty v_accvgpr_read / _write / _mov per
+// eight MFMAs), and the loop then measures those moves (23 cycles per instruction) instead of the matrix pipe.
+// Check the loop with -save-temps: it must be eight (four) back-to-back MFMAs, two scalar
+// instructions and the branch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,9 +57,10 @@ int main() {
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       unsigned long long c[2]; CHECK(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
       const double flops = 256.0 * 4 * iters * 4 * 32768.0;
-      printf("%s: %.2f ms  %.0f TFLOP/s  shader clock %.2f GHz  cycles per 32K-FLOP %.1f\n",
-             form == 32 ? "32x32x16" : "16x16x32", ms, flops / ms / 1e9, (double)c[0] / ((double)c[1] * 10.0) ,
-             (double)c[0] / (iters * 4.0));
+      const double per_iter = form == 32 ? 4.0 : 8.0;     // MFMA instructions per loop iteration
+      printf("%s: %.2f ms  %.0f TFLOP/s  shader clock %.2f GHz  cycles per instruction %.1f  (per 32K FLOP %.1f)\n",
+             form == 32 ? "32x32x16" : "16x16x32", ms, flops / ms / 1e9, (double)c[0] / ((double)c[1] * 10.0),
+             (double)c[0] / (iters * per_iter), (double)c[0] / (iters * 4.0));
     }
   return 0;
 }
