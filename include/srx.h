@@ -37,7 +37,8 @@ int srx_version(void);
 const char* srx_last_error(void);
 /* sizeof() of the ABI structs, for binding self-checks: 0 srx_conv_desc, 1 srx_wgrad_task,
  * 2 srx_wgrad_desc, 3 srx_pack_seg, 4 srx_pack_layer, 5 srx_unpack_item, 6 srx_sn_layer,
- * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop; -1 for an unknown id. */
+ * 7 srx_sn_bwd_layer, 8 srx_generic_args, 9 srx_op, 10 srx_tile, 11 srx_crop, 12 srx_rdb_desc; -1 for an
+ * unknown id. */
 int srx_sizeof(int which);
 /* Host-side self-check (no GPU call): kernel attributes such as the dynamic LDS limit are set
  * once per DEVICE a kernel is launched on, not once per process.  0 = ok.  No counterpart in the
@@ -120,6 +121,35 @@ typedef struct srx_conv_desc {
  * esrgan/discriminator.py:12-13,30-32; VGG conv+ReLU, utils/loss.py:15), and,
  * with transposed/flipped packed weights, the data gradient of the same. */
 int srx_conv2d(const srx_conv_desc* d, void* stream);
+
+/* ------------------------------------------------- fused dense block (forward) */
+/* ResidualDenseBlock.forward (esrgan/generator.py:17-23) — five convolutions over the growing
+ * channel stack, LeakyReLU(0.2) on the first four, conv5 * 0.2 + x — in ONE launch, optionally
+ * with the enclosing RRDB's out * 0.2 + x (:37) folded into the same epilogue:
+ *     y = alpha * conv5(cat(x, x1..x4)) + beta1 * x + beta2 * res2.
+ * buf is the block's C8 buffer of nf + 4 gc channels: planes [0, nf/8) hold x on entry; with
+ * store_growth the growth slices x1..x4 are written to the planes behind them (the backward pass
+ * reads them), without it only y is written (inference).  w / bias: the five layers packed by
+ * srx_pack_weights (perm 0), laid out back to back in conv1..conv5 order (52 chunks of 9 x 512
+ * elements; 4 x 32 + 64 bias floats).  bf16, nf = 64, gc = 32 only; same results, bit for bit, as
+ * five srx_conv2d calls. */
+typedef struct srx_rdb_desc {
+  int32_t dtype;         /* SRX_BF16                                                   */
+  int32_t B, H, W;
+  int32_t nf, gc;        /* 64, 32                                                     */
+  int32_t store_growth;  /* 1: x1..x4 written to buf planes [nf/8, (nf+4gc)/8)           */
+  int32_t pad_;
+  void* buf; int64_t buf_img_stride;
+  void* y;   int64_t y_img_stride;
+  const void* w;
+  const float* bias;
+  float act_slope;       /* 0.2                                                        */
+  float alpha;
+  float beta1;
+  float beta2;
+  const void* res2; int64_t res2_img_stride;   /* NULL: no second residual             */
+} srx_rdb_desc;
+int srx_rdb_forward(const srx_rdb_desc* d, void* stream);
 
 /* --------------------------------------------------------- weight gradients */
 /* One 64x64 (cin x cout) block task of a weight-gradient launch: four 32x32
@@ -357,6 +387,7 @@ int srx_crop_augment(const srx_crop* crops /*DEVICE*/, int B, int size, float* o
 #define SRX_OP_GAP_FWD 10
 #define SRX_OP_GAP_BWD 11
 #define SRX_OP_ACT_BWD 12
+#define SRX_OP_RDB_FWD 13
 
 typedef struct srx_generic_args {   /* for the bandwidth-bound helpers */
   int32_t dtype, B, C, H, W, noct;
@@ -375,6 +406,7 @@ typedef struct srx_op {
     srx_conv_desc conv;
     srx_wgrad_desc wgrad;
     srx_generic_args g;
+    srx_rdb_desc rdb;
   } u;
 } srx_op;
 

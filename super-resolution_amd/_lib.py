@@ -22,6 +22,7 @@ BF16, F32 = 0, 1
 OP_CONV, OP_WGRAD, OP_PIXEL_UNSHUFFLE, OP_CHANNEL_SUM, OP_ZERO_STUFF = 1, 2, 3, 4, 5
 OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_MEMSET, OP_AXPBY, OP_GAP_FWD, OP_GAP_BWD = 6, 7, 8, 9, 10, 11
 OP_ACT_BWD = 12
+OP_RDB_FWD = 13
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -92,8 +93,16 @@ class Crop(C.Structure):
     _fields_ = [("img", vp), ("H", i32), ("W", i32), ("y0", i32), ("x0", i32), ("flags", i32), ("pad_", i32)]
 
 
+class RdbDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("nf", i32), ("gc", i32),
+                ("store_growth", i32), ("pad_", i32),
+                ("buf", vp), ("buf_img_stride", i64), ("y", vp), ("y_img_stride", i64),
+                ("w", vp), ("bias", vp), ("act_slope", f32), ("alpha", f32), ("beta1", f32), ("beta2", f32),
+                ("res2", vp), ("res2_img_stride", i64)]
+
+
 class _OpU(C.Union):
-    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs)]
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("g", GenericArgs), ("rdb", RdbDesc)]
 
 
 class Op(C.Structure):
@@ -112,6 +121,7 @@ _SIGS = {
     "srx_pack_weights_flat": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "srx_conv2d": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "srx_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
+    "srx_rdb_forward": (C.c_int, [C.POINTER(RdbDesc), vp]),
     "srx_unpack_wgrad": (C.c_int, [vp, C.c_int, i64, vp]),
     "srx_channel_sum": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
     "srx_pixel_unshuffle2": (C.c_int, [C.c_int, vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -162,7 +172,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         structs = (ConvDesc, WgradTask, WgradDesc, PackSeg, PackLayer, UnpackItem, SnLayer,
-                   SnBwdLayer, GenericArgs, Op, Tile, Crop)
+                   SnBwdLayer, GenericArgs, Op, Tile, Crop, RdbDesc)
         for i, st in enumerate(structs):
             if l.srx_sizeof(i) != C.sizeof(st):
                 raise RuntimeError(f"libsrx ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in "

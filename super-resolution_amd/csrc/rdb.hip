@@ -1,0 +1,362 @@
+// ResidualDenseBlock forward (esrgan/generator.py:17-23, with the RRDB tail of :37) as ONE launch.
+//
+// The five convolutions of a dense block re-read the block input and every earlier growth slice:
+// run layer by layer they are five dependent launches whose fixed cost (launch boundary, prologue,
+// epilogue drain: about 4.5 us each) outweighs their arithmetic on small feature maps.  Here a
+// workgroup owns a 16 x 8 pixel tile of the block's output and computes all five layers for it:
+//   * the block input x (64 channels) is staged ONCE into LDS over the tile plus a 5-pixel halo;
+//   * layer k (k = 1..4) computes its 32 channels over the tile plus a (5 - k)-pixel halo (the
+//     halo is recomputed by the neighbouring tiles: 1.5 x the arithmetic of the layer-by-layer
+//     form), applies bias + LeakyReLU, and leaves them in LDS for the layers behind it (and, for
+//     training, stores the tile's own pixels to the block buffer for the backward pass);
+//   * layer 5 computes the 64 output channels of the tile as two 32-channel passes and applies
+//     alpha * y + beta1 * x + beta2 * res2.
+// Only weights stream during the launch: one 16-input-channel chunk (9 taps x 32 x 16, 9 KB) per
+// step through a three-stage LDS ring filled by LDS-DMA, one counted s_waitcnt vmcnt and one raw
+// s_barrier per chunk, 52 chunks per tile.  The GEMM view, the fragment layouts, the packed
+// weight format and the order of every floating-point operation are those of conv_kernel
+// (conv.hip), so the results equal the layer-by-layer path bit for bit.
+//
+// bf16, 64 block channels, 32 growth channels only (what the reference instantiates,
+// esrgan/generator.py:8,27); other shapes take the layer-by-layer path.
+#include <stdlib.h>
+#include <utility>
+#include "srx_common.h"
+
+namespace {
+
+constexpr int TW = 16, TH = 8, HALO = 5;
+constexpr int reg_h(int halo) { return TH + 2 * halo; }
+constexpr int reg_w(int halo) { return TW + 2 * halo; }
+constexpr int reg_p(int halo) { return reg_h(halo) * reg_w(halo); }
+// source s of a layer's input: 0 = block input (8 octet planes, halo 5); s = 1..4 = growth slice s
+// (4 planes, halo 5 - s).  Regions are stored [plane][pixel of the region], 16-byte slots.
+constexpr int src_halo(int s) { return HALO - s; }
+constexpr int src_planes(int s) { return s == 0 ? 8 : 4; }
+constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * reg_p(src_halo(s - 1)); }
+constexpr int ACT_SLOTS = src_base(5);
+static_assert(ACT_SLOTS == 8192, "activation regions");
+constexpr int WSTAGE = 9 * 64;                    // one chunk of one 32-channel block: 9 taps x 64 slots
+constexpr int NSTG = 3;
+constexpr int W_BASE = ACT_SLOTS;
+constexpr int DUMP_BASE = W_BASE + NSTG * WSTAGE; // where the out-of-range part of a staging instruction lands
+constexpr int BIAS_BASE = DUMP_BASE + 64;         // packed biases: 4 x 32 + 64 floats = 48 slots
+constexpr int LDS_SLOTS = BIAS_BASE + 64;
+constexpr int LDS_BYTES = LDS_SLOTS * 16;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int X_SLOTS = src_planes(0) * reg_p(HALO);          // 3744
+constexpr int X_DMA = (X_SLOTS + 255) / 256;                   // staging instructions per wave for x
+constexpr int NCHUNK_TOTAL = 4 + 6 + 8 + 10 + 2 * 12;          // weight chunks per tile
+constexpr unsigned WCHUNK_BYTES = 9 * 512 * 2;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+// layer L = 0..4 (conv1..conv5): output halo, pixel groups of 32, groups per wave
+constexpr int out_halo(int L) { return L < 4 ? HALO - 1 - L : 0; }
+constexpr int out_p(int L) { return reg_p(out_halo(L)); }
+constexpr int out_groups(int L) { return (out_p(L) + 31) / 32; }            // 12 10 8 6 4
+constexpr int rw_max(int L) { return (out_groups(L) + 3) / 4; }             // 3 3 2 2 1
+// which waves take the odd groups alternates between the layers that have them
+constexpr int wave_rot(int L) { return L == 3 ? 2 : 0; }
+constexpr int bias_off(int L) { return 32 * L; }                            // floats; conv5: + 32 * pass
+
+struct RdbParams {
+  bf16* buf; long buf_is;           // block buffer, 24 octet planes per image
+  bf16* y; long y_is;               // output view, 8 planes
+  const bf16* w; const float* bias;
+  const bf16* res2; long r2_is;
+  float slope, alpha, beta1, beta2;
+  int H, W, tiles_x, tiles_y, total;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__device__ __forceinline__ void mma16(const bf16x8& a, const bf16x8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// One 16-channel chunk of one layer for R pixel groups: A = the chunk's weight block in ring stage
+// sw, B = the activation fragments at the nine tap shifts.  Fragment reads run one tap row ahead
+// of the MFMAs (same order of accumulation as conv_kernel: tap rows, taps, groups).
+template <int R>
+__device__ __forceinline__ void chunk_mma(const bf16x8* __restrict__ sw, const bf16x8* __restrict__ sx, int ws,
+                                          const int* ps, f32x16* acc, int pl, int hh) {
+  bf16x8 wf[2][3], xf[2][3][R];
+  auto read_row = [&](int dy, int buf) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      wf[buf][dx] = sw[((dy * 3 + dx) * 2 + hh) * 32 + pl];
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) xf[buf][dx][rg] = sx[ps[rg] + dy * ws + dx];
+    }
+  };
+  read_row(0, 0);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    if (dy + 1 < 3) read_row(dy + 1, (dy + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) mma16(wf[dy & 1][dx], xf[dy & 1][dx][rg], acc[rg]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, pl = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // workgroup -> tile, one contiguous run of tiles per XCD (neighbouring tiles share most of their
+  // halo: they should meet in one XCD's L2)
+  unsigned t = blockIdx.x;
+  {
+    const unsigned chunk = (unsigned)p.total / 8u;
+    if (t < 8u * chunk) t = (t & 7u) * chunk + (t >> 3);
+  }
+  const int tx = (int)(t % (unsigned)p.tiles_x);
+  const unsigned tr = t / (unsigned)p.tiles_x;
+  const int ty = (int)(tr % (unsigned)p.tiles_y), b = (int)(tr / (unsigned)p.tiles_y);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int H = p.H, W = p.W;
+  const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
+
+  // packed biases -> LDS (oldest memory operation of the wave: its wait leaves the staging in flight)
+  f32x4 bias_in = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 48) bias_in = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+
+  bf16* const img = p.buf + (long)b * p.buf_is;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(8u * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(24u * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.y_is, 0, (int)(8u * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)(NCHUNK_TOTAL * WCHUNK_BYTES), 0x00020000);
+
+  // ---- the block input over the tile + 5-pixel halo: X_DMA LDS-DMA instructions per wave; pixels
+  // outside the image (the zero padding) and the slots past the region get an out-of-range offset,
+  // for which the hardware deposits zeros (the few slots past the region belong to growth slice 1,
+  // which is written later)
+#pragma unroll
+  for (int j = 0; j < X_DMA; ++j) {
+    const unsigned slot = (unsigned)(j * 256 + tid);
+    const unsigned q = slot / (unsigned)reg_p(HALO), pix = slot - q * (unsigned)reg_p(HALO);
+    const unsigned r = pix / (unsigned)reg_w(HALO), c = pix - r * (unsigned)reg_w(HALO);
+    const int gy = oy0 - HALO + (int)r, gx = ox0 - HALO + (int)c;
+    const bool ok = (slot < (unsigned)X_SLOTS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+    const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
+  }
+  // ---- weights: chunk n of the tile's 52 lives at n * WCHUNK_BYTES of the packed block
+  const unsigned woff0 = (unsigned)tid * 16u, woff1 = (unsigned)(256 + tid) * 16u;
+  const unsigned woff2 = tid < 64 ? (unsigned)(512 + tid) * 16u : OOB;
+  auto issue_w = [&](int n, int stage) {
+    u32x4_* st = smem + W_BASE + stage * WSTAGE;
+    const unsigned base = (unsigned)n * WCHUNK_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st + wave_u * 64), 16, woff0 + base, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st + 256 + wave_u * 64), 16, woff1 + base, 0, 0, 0);
+    // the last 64 slots of a chunk are wave 0's; the other waves issue the same instruction with
+    // every lane out of range (so that each wave counts three per chunk) into a dump area
+    u32x4_* d2 = wave_u == 0 ? st + 512 : smem + DUMP_BASE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)d2, 16, woff2 == OOB ? OOB : woff2 + base, 0, 0, 0);
+  };
+  issue_w(0, 0);
+  issue_w(1, 1);
+  if (tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = bias_in;
+  // the biases are the accumulators' initial values: written by wave 0, read by every wave before
+  // its first chunk step
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const bf16x8* const lds = reinterpret_cast<const bf16x8*>(smem);
+  bf16x8* const ldsw = reinterpret_cast<bf16x8*>(smem);
+  const float* const lbias = reinterpret_cast<const float*>(smem + BIAS_BASE);
+
+  int n = 0, stage = 0;
+  int extra = 0;             // global stores this wave has issued since its last counted wait
+
+  // one chunk step of the ring: chunk n has landed in every wave, chunk n + 2 goes out
+  auto step_begin = [&]() {
+    if (n + 1 >= NCHUNK_TOTAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (extra == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (extra == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (extra == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    extra = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes of the previous layer
+    __builtin_amdgcn_s_barrier();
+    if (n + 2 < NCHUNK_TOTAL) issue_w(n + 2, stage >= 1 ? stage - 1 : NSTG - 1);
+  };
+  auto step_end = [&]() {
+    ++n;
+    stage = stage == NSTG - 1 ? 0 : stage + 1;
+  };
+
+  static_for<5>([&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
+    constexpr int NPASS = L == 4 ? 2 : 1;
+    // this wave's pixel groups: g = rg * 4 + ((wave + rot) & 3); only the last rg can be missing
+    const int wsel = (wave_u + wave_rot(L)) & 3;
+    const bool last_valid = (RW - 1) * 4 + wsel < NG;                  // wave-uniform
+    int py[RW], px[RW], pp[RW];
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg) {
+      pp[rg] = (rg * 4 + wsel) * 32 + pl;
+      const int pc = pp[rg] < OP ? pp[rg] : OP - 1;
+      py[rg] = pc / OWd;
+      px[rg] = pc - py[rg] * OWd;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      f32x16 acc[RW];
+      {
+        const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + 32 * pass + hh * 16);
+        const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
+          }
+      }
+      // K loop: sources in channel order (block input, then the growth slices), 16 channels a step
+      static_for<L + 1>([&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
+        constexpr int O = L - S;                     // offset of this layer's region inside the source's, minus the tap pad
+        int ps[RW];
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) ps[rg] = (py[rg] + O) * SW + px[rg] + O;
+        for (int cc = 0; cc < (S == 0 ? 4 : 2); ++cc) {
+          step_begin();
+          const bf16x8* sw = lds + W_BASE + stage * WSTAGE;
+          const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP;
+          if (RW == 1 || last_valid) chunk_mma<RW>(sw, sx, SW, ps, acc, pl, hh);
+          else chunk_mma<(RW > 1 ? RW - 1 : 1)>(sw, sx, SW, ps, acc, pl, hh);
+          step_end();
+        }
+      });
+
+      if constexpr (L < 4) {
+        // bias is in the accumulators; LeakyReLU; zero outside the image (the next layer's padding);
+        // into LDS for the layers behind, and the tile's own pixels to the block buffer
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) {
+          const bool has = rg < RW - 1 || last_valid;                 // wave-uniform
+          const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
+          const bool lane_ok = has && pp[rg] < OP;
+          const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+          const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = acc[rg][j * 8 + e];
+              v = fmaxf(v, v * p.slope);
+              o[e] = (bf16)(in_img ? v : 0.f);
+            }
+            const int oct = 2 * j + hh;
+            if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
+            if constexpr (STORE) {
+              const unsigned off = own ? (unsigned)(8 + 4 * L + oct) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), grsrc, off, 0, 0);
+            }
+          }
+        }
+        if constexpr (STORE) extra = 2 * RW;
+      } else {
+        // conv5: alpha * y + beta1 * x + beta2 * res2 for the 32 channels of this pass
+        const int gy = oy0 + py[0], gx = ox0 + px[0];
+        const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        const int xs = (py[0] + HALO) * reg_w(HALO) + px[0] + HALO;
+        bf16x8 r2[2];
+        if (p.res2 != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int oct = pass * 4 + 2 * j + hh;
+            if (in_img)
+              r2[j] = *reinterpret_cast<const bf16x8*>(p.res2 + (long)b * p.r2_is + (long)oct * ((long)H * W * 8) +
+                                                       ((long)gy * W + gx) * 8);
+          }
+        }
+        if (p.alpha != 1.f) acc[0] *= p.alpha;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oct = pass * 4 + 2 * j + hh;
+          const bf16x8 xr = lds[src_base(0) + oct * reg_p(HALO) + xs];
+          const float b1 = p.beta1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[0][j * 8 + e] += b1 * (float)xr[e];
+        }
+        if (p.res2 != nullptr) {
+          const float b2 = p.beta2;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[0][j * 8 + e] += b2 * (float)r2[j][e];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oct = pass * 4 + 2 * j + hh;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[0][j * 8 + e];
+          const unsigned off = in_img ? (unsigned)oct * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
+        }
+        extra = 2;
+      }
+    }
+  });
+}
+
+}  // namespace
+
+extern "C" int srx_rdb_forward(const srx_rdb_desc* d, void* stream) {
+  SRX_CHECK_ARG(d != nullptr, "srx_rdb_forward: null descriptor");
+  SRX_CHECK_ARG(d->dtype == SRX_BF16, "srx_rdb_forward: bf16 only (got dtype %d)", d->dtype);
+  SRX_CHECK_ARG(d->nf == 64 && d->gc == 32, "srx_rdb_forward: 64 block channels and 32 growth channels only (got %d, %d)",
+                d->nf, d->gc);
+  SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0, "srx_rdb_forward: non-positive size");
+  SRX_CHECK_ARG(d->buf && d->y && d->w && d->bias, "srx_rdb_forward: null buf / y / w / bias pointer");
+  SRX_CHECK_ARG(((uintptr_t)d->buf | (uintptr_t)d->y | (uintptr_t)d->w | (uintptr_t)d->bias | (uintptr_t)d->res2) % 16 == 0,
+                "srx_rdb_forward: pointers must be 16-byte aligned");
+  // one image's 24 planes are addressed through a 32-bit buffer descriptor
+  SRX_CHECK_ARG((long)d->H * d->W * 16 * 24 < 0x7FFFFFF0L, "srx_rdb_forward: image of %d x %d is too large for one launch; "
+                "tile the image", d->H, d->W);
+  RdbParams p;
+  p.buf = static_cast<bf16*>(d->buf); p.buf_is = d->buf_img_stride;
+  p.y = static_cast<bf16*>(d->y); p.y_is = d->y_img_stride;
+  p.w = static_cast<const bf16*>(d->w); p.bias = d->bias;
+  p.res2 = static_cast<const bf16*>(d->res2); p.r2_is = d->res2_img_stride;
+  p.slope = d->act_slope; p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2;
+  p.H = d->H; p.W = d->W;
+  p.tiles_x = (d->W + TW - 1) / TW;
+  p.tiles_y = (d->H + TH - 1) / TH;
+  const long total = (long)p.tiles_x * p.tiles_y * d->B;
+  SRX_CHECK_ARG(total < (1L << 31), "srx_rdb_forward: grid out of range");
+  p.total = (int)total;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->store_growth) {
+    static srx_per_device_once attr;
+    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_fwd_kernel<true>), LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(rdb_fwd_kernel<true>, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+  } else {
+    static srx_per_device_once attr;
+    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_fwd_kernel<false>), LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(rdb_fwd_kernel<false>, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+  }
+  return srx_check_launch("rdb_fwd_kernel");
+}

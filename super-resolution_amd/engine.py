@@ -173,15 +173,25 @@ class Plan:
 
     # ----------------------------------------------------------- packing
     def packed_layer(self, cout: int, cin: int, taps: int, perm: int,
-                     segs: Sequence[dict], bias_ptr: int = 0, with_bias: bool = True):
-        """Register a virtual conv layer to pack; returns (w_ptr, bias_ptr)."""
+                     segs: Sequence[dict], bias_ptr: int = 0, with_bias: bool = True,
+                     dst_w: Optional[torch.Tensor] = None, dst_bias: Optional[torch.Tensor] = None):
+        """Register a virtual conv layer to pack; returns (w_ptr, bias_ptr).  dst_w / dst_bias:
+        where to pack it (slices of a caller-owned tensor: the fused dense block wants its five
+        layers back to back); by default the layer gets tensors of its own."""
         nblk, nchunk = _ceil(cout, 32), _ceil(cin, 16)
         nel = nblk * nchunk * taps * 512
-        w = torch.empty(nel, dtype=self.tdtype, device=self.device)
-        self.keep.append(w)
-        self.bytes_alloc += nel * self.esize
+        if dst_w is not None:
+            assert dst_w.numel() == nel and dst_w.dtype == self.tdtype and dst_w.is_contiguous()
+            w = dst_w
+        else:
+            w = torch.empty(nel, dtype=self.tdtype, device=self.device)
+            self.keep.append(w)
+            self.bytes_alloc += nel * self.esize
         bias = None
-        if with_bias:
+        if with_bias and dst_bias is not None:
+            assert dst_bias.numel() == nblk * 32 and dst_bias.dtype == torch.float32
+            bias = dst_bias
+        elif with_bias:
             bias = self.f32(nblk * 32)
         self.packed_tensors.append((w, bias))
         lay = L.PackLayer()
@@ -638,10 +648,33 @@ class _GenBase(Plan):
     def sp(self, name: str) -> int:
         return self.stage.data_ptr() + 4 * self._soff[name]
 
-    def fwd_layer(self, P, name, perm=0):
+    def fwd_layer(self, P, name, perm=0, dst_w=None, dst_bias=None):
         wt = P[name + ".weight"]
         return self.packed_layer(wt.shape[0], wt.shape[1], 9, perm, [conv_seg(wt)],
-                                 P[name + ".bias"].data_ptr())
+                                 P[name + ".bias"].data_ptr(), dst_w=dst_w, dst_bias=dst_bias)
+
+    # One launch per dense block forward (csrc/rdb.hip) where the shape allows it: bf16, 64 block
+    # channels, 32 growth channels.  SRX_FUSED_RDB=0 keeps the five-launch form (A/B runs, tests).
+    fused_rdb = os.environ.get("SRX_FUSED_RDB", "1") != "0"
+
+    def rdb_fwd(self, ops: list, cur: Buf, dst: View, w_ptr: int, bias_ptr: int, B: int, h: int, w: int,
+                nf: int, gc: int, store_growth: bool, alpha: float, beta1: float,
+                res2: Optional[View] = None, beta2: float = 0.0):
+        op = L.Op()
+        op.kind = L.OP_RDB_FWD
+        d = op.u.rdb
+        d.dtype, d.B, d.H, d.W, d.nf, d.gc = self.dt, B, h, w, nf, gc
+        d.store_growth = 1 if store_growth else 0
+        d.buf, d.buf_img_stride = cur.ptr(0), cur.img_stride
+        d.y, d.y_img_stride = dst[0].ptr(dst[1]), dst[0].img_stride
+        d.w, d.bias = w_ptr, bias_ptr
+        d.act_slope, d.alpha, d.beta1, d.beta2 = LRELU, alpha, beta1, beta2
+        if res2 is not None:
+            d.res2, d.res2_img_stride = res2[0].ptr(res2[1]), res2[0].img_stride
+        ops.append(op)
+        if isinstance(ops, OpList):
+            macs = sum(9 * (nf + k * gc) * gc for k in range(4)) + 9 * (nf + 4 * gc) * nf
+            ops.meta.append(("rdb_fwd_kernel", 2.0 * B * h * w * macs))
 
     def dgrad_layer(self, P, name, cout_v):
         wt = P[name + ".weight"]
@@ -659,6 +692,25 @@ class _GenBase(Plan):
         """ResidualDenseBlock.forward (esrgan/generator.py:17-23); q == 2 also applies the
         enclosing RRDB's ``out*0.2 + x`` (:37) in the same epilogue."""
         nf8, gc8 = nf // 8, gc // 8
+        if self.fused_rdb and self.dt == L.BF16 and (nf, gc) == (64, 32):
+            # the five layers packed back to back: conv1..conv4 (4, 6, 8, 10 chunks of 9 x 512), conv5 (2 x 12)
+            chunks = [(nf + k * gc) // 16 for k in range(4)] + [2 * (nf + 4 * gc) // 16]
+            w_all = torch.empty(sum(chunks) * 9 * 512, dtype=self.tdtype, device=self.device)
+            b_all = self.f32(4 * 32 + 64)
+            self.keep.append(w_all)
+            self.bytes_alloc += w_all.numel() * self.esize
+            wo = bo = 0
+            for k in range(1, 6):
+                nw, nb_ = chunks[k - 1] * 9 * 512, (32 if k < 5 else 64)
+                self.fwd_layer(P, pre + f"conv{k}", dst_w=w_all[wo:wo + nw], dst_bias=b_all[bo:bo + nb_])
+                wo, bo = wo + nw, bo + nb_
+            if q < 2:
+                self.rdb_fwd(ops, cur, dst, w_all.data_ptr(), b_all.data_ptr(), B, h, w, nf, gc, self.need_grad,
+                             RES, 1.0)
+            else:
+                self.rdb_fwd(ops, cur, dst, w_all.data_ptr(), b_all.data_ptr(), B, h, w, nf, gc, self.need_grad,
+                             RES * RES, RES, rrdb_in, 1.0)
+            return
         packed = {k: self.fwd_layer(P, pre + f"conv{k}") for k in range(1, 5)}
         for k in range(1, 5):
             self.conv(ops, (cur, 0), (cur, nf8 + (k - 1) * gc8), packed[k][0], packed[k][1], B, h, w,

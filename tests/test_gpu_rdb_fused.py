@@ -1,0 +1,73 @@
+"""The fused dense-block forward (srx_rdb_forward, one launch per ResidualDenseBlock) against the
+layer-by-layer path (five srx_conv2d launches): the same bits, for training plans (growth slices
+stored for the backward pass) and inference plans (only the block output written), on image
+sizes that are and are not multiples of the 16 x 8 tile, including images smaller than a tile."""
+import pytest
+import torch
+
+from helpers import O, fill_module_, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _plans(shape, need_grad, num_blocks=2):
+    E, G = pkg("engine"), pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=51).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    B, h, w = shape
+    out = []
+    for fused in (False, True):
+        E._GenBase.fused_rdb = fused
+        try:
+            out.append(E.GeneratorPlan(params, B, h, w, torch.bfloat16, num_blocks=num_blocks, need_grad=need_grad))
+        finally:
+            E._GenBase.fused_rdb = True
+    names = [[m[0] for m in p.fwd_meta] for p in out]
+    assert "rdb_fwd_kernel" not in names[0] and names[1].count("rdb_fwd_kernel") == 3 * num_blocks
+    return out
+
+
+@pytest.mark.parametrize("need_grad", [True, False])
+@pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
+def test_fused_block_forward_equals_layer_by_layer(shape, need_grad):
+    ref, fus = _plans(shape, need_grad)
+    x = O.hash_input("fr.x", (shape[0], 3, shape[1], shape[2])).cuda()
+    y0 = ref.forward(x)
+    y1 = fus.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y0).all() and float(y0.abs().max()) > 0
+    assert torch.equal(y0, y1)
+    if need_grad:
+        # every dense block's buffer: input planes and the four growth slices the backward pass reads
+        # (the last buffer only ever receives the trunk's output in its first 8 planes)
+        B, hw8 = shape[0], shape[1] * shape[2] * 8
+        for r, (a, b) in enumerate(zip(ref.R, fus.R)):
+            planes = 24 if r + 1 < len(ref.R) else 8
+            va = a.t.view(torch.int16).view(B, 24, hw8)[:, :planes]
+            vb = b.t.view(torch.int16).view(B, 24, hw8)[:, :planes]
+            assert torch.equal(va, vb), f"block buffer {r} differs"
+
+
+def test_fused_block_backward_uses_the_stored_growth_slices():
+    """Forward fused, backward layer by layer: gradients equal those of the all-layer-by-layer plan
+    up to the summation order of the weight-gradient atomics."""
+    ref, fus = _plans((2, 24, 40), True)
+    x = O.hash_input("fr.x2", (2, 3, 24, 40)).cuda()
+    gy = O.hash_input("fr.gy", (2, 3, 96, 160)).cuda() / (2 * 3 * 96 * 160)
+    for p in (ref, fus):
+        p.forward(x)
+        p.backward(gy)
+    torch.cuda.synchronize()
+    a, b = ref.flat_grad, fus.flat_grad
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+def test_fused_block_rejects_what_it_does_not_cover():
+    L = pkg("_lib")
+    lib = L.lib()
+    d = L.RdbDesc(dtype=L.F32, B=1, H=8, W=8, nf=64, gc=32)
+    assert lib.srx_rdb_forward(d, None) == 1 and b"bf16 only" in lib.srx_last_error()
+    d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=32, gc=16)
+    assert lib.srx_rdb_forward(d, None) == 1 and b"64 block channels" in lib.srx_last_error()
+    assert lib.srx_rdb_forward(None, None) == 1

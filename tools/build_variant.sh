@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../super-resolution_amd/csrc"
 mkdir -p ../../tools/variants/obj_$1
-for f in api conv wgrad elementwise tiles; do
+for f in api conv wgrad elementwise tiles rdb; do
   EX=""; [ $f = wgrad ] && EX="-mllvm -amdgpu-mfma-vgpr-form"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-function $EX $2 -c $f.hip -o ../../tools/variants/obj_$1/$f.o &
 done
