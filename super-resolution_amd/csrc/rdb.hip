@@ -11,11 +11,16 @@
 //     training, stores the tile's own pixels to the block buffer for the backward pass);
 //   * layer 5 computes the 64 output channels of the tile as two 32-channel passes and applies
 //     alpha * y + beta1 * x + beta2 * res2.
-// Only weights stream during the launch: one 16-input-channel chunk (9 taps x 32 x 16, 9 KB) per
-// step through a three-stage LDS ring filled by LDS-DMA, one counted s_waitcnt vmcnt and one raw
-// s_barrier per chunk, 52 chunks per tile.  The GEMM view, the fragment layouts, the packed
-// weight format and the order of every floating-point operation are those of conv_kernel
-// (conv.hip), so the results equal the layer-by-layer path bit for bit.
+// Only weights stream during the launch, and they never touch LDS: each lane reads its own 16-byte
+// fragment of a 16-input-channel chunk (9 taps x 32 x 16, 9 KB, the same for the four waves: L1
+// hits) into registers one chunk ahead of the multiply.  With the activations resident in LDS and
+// the weights in registers a layer needs no synchronisation at all: one barrier per LAYER (five
+// per tile), where the layer-by-layer kernel has one per 16-channel chunk (52).  A first version
+// that staged the weights through an LDS ring (one counted wait + one barrier per chunk) took
+// 61 us per block at 16 x 64 x 64 against 51 us for the five launches.
+// The GEMM view, the fragment layouts, the packed weight format and the order of every
+// floating-point operation are those of conv_kernel (conv.hip), so the results equal the
+// layer-by-layer path bit for bit.
 //
 // bf16, 64 block channels, 32 growth channels only (what the reference instantiates,
 // esrgan/generator.py:8,27); other shapes take the layer-by-layer path.
@@ -36,11 +41,7 @@ constexpr int src_planes(int s) { return s == 0 ? 8 : 4; }
 constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * reg_p(src_halo(s - 1)); }
 constexpr int ACT_SLOTS = src_base(5);
 static_assert(ACT_SLOTS == 8192, "activation regions");
-constexpr int WSTAGE = 9 * 64;                    // one chunk of one 32-channel block: 9 taps x 64 slots
-constexpr int NSTG = 3;
-constexpr int W_BASE = ACT_SLOTS;
-constexpr int DUMP_BASE = W_BASE + NSTG * WSTAGE; // where the out-of-range part of a staging instruction lands
-constexpr int BIAS_BASE = DUMP_BASE + 64;         // packed biases: 4 x 32 + 64 floats = 48 slots
+constexpr int BIAS_BASE = ACT_SLOTS;              // packed biases: 4 x 32 + 64 floats = 48 slots
 constexpr int LDS_SLOTS = BIAS_BASE + 64;
 constexpr int LDS_BYTES = LDS_SLOTS * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -82,20 +83,23 @@ __device__ __forceinline__ void mma16(const bf16x8& a, const bf16x8& b, f32x16& 
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// One 16-channel chunk of one layer for R pixel groups: A = the chunk's weight block in ring stage
-// sw, B = the activation fragments at the nine tap shifts.  Fragment reads run one tap row ahead
-// of the MFMAs (same order of accumulation as conv_kernel: tap rows, taps, groups).
-template <int R>
-__device__ __forceinline__ void chunk_mma(const bf16x8* __restrict__ sw, const bf16x8* __restrict__ sx, int ws,
-                                          const int* ps, f32x16* acc, int pl, int hh) {
-  bf16x8 wf[2][3], xf[2][3][R];
+// One 16-channel chunk of one layer for R pixel groups: A = the chunk's nine weight fragments (in
+// registers), B = the activation fragments at the nine tap shifts, read from the LDS-resident
+// regions one tap row ahead of the MFMAs (same order of accumulation as conv_kernel: tap rows,
+// taps, groups).
+template <int R, bool PREFETCH>
+__device__ __forceinline__ void chunk_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)[9], __amdgpu_buffer_rsrc_t wrsrc,
+                                          unsigned wlane, unsigned wnext_off, const bf16x8* __restrict__ sx, int ws,
+                                          const int* ps, f32x16* acc) {
+  bf16x8 xf[2][3][R];
   auto read_row = [&](int dy, int buf) {
+#ifdef RDB_ABLATE_NO_XREAD
+    if (dy > 0) return;                       // timing-only build: one tap row of activation fragments per chunk
+#endif
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      wf[buf][dx] = sw[((dy * 3 + dx) * 2 + hh) * 32 + pl];
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int rg = 0; rg < R; ++rg) xf[buf][dx][rg] = sx[ps[rg] + dy * ws + dx];
-    }
   };
   read_row(0, 0);
 #pragma unroll
@@ -103,11 +107,32 @@ __device__ __forceinline__ void chunk_mma(const bf16x8* __restrict__ sw, const b
     if (dy + 1 < 3) read_row(dy + 1, (dy + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+    for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-      for (int rg = 0; rg < R; ++rg) mma16(wf[dy & 1][dx], xf[dy & 1][dx][rg], acc[rg]);
+      for (int rg = 0; rg < R; ++rg) {
+#ifdef RDB_ABLATE_NO_MMA
+        if (dy + dx > 0) { asm volatile("" :: "v"(xf[dy & 1][dx][rg]), "v"(wf[dy * 3 + dx])); continue; }   // timing-only build
+#endif
+        mma16(__builtin_bit_cast(bf16x8, wf[dy * 3 + dx]), xf[dy & 1][dx][rg], acc[rg]);
+      }
+      // the weight fragment of the same tap of a later chunk, one load per tap: nine loads issued
+      // back to back by four waves at once queue up in the address unit (16 cycles each) and hold
+      // the instruction stream, and with it the MFMAs, for their whole length
+      if constexpr (PREFETCH) {
+#ifndef RDB_ABLATE_NO_WLOAD
+        wnext[dy * 3 + dx] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)(dy * 3 + dx) * 1024u, wnext_off, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// chunk index (0..51) of (layer, pass, source, chunk of the source) in the packed weight block
+constexpr int layer_chunk0(int L) { return L == 0 ? 0 : L == 1 ? 4 : L == 2 ? 10 : L == 3 ? 18 : 28; }
+constexpr int chunk_index(int L, int pass, int S, int cc) {
+  return layer_chunk0(L) + 12 * pass + (S == 0 ? 0 : 4 + 2 * (S - 1)) + cc;
 }
 
 template <bool STORE>
@@ -131,10 +156,6 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
   const int H = p.H, W = p.W;
   const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
 
-  // packed biases -> LDS (oldest memory operation of the wave: its wait leaves the staging in flight)
-  f32x4 bias_in = {0.f, 0.f, 0.f, 0.f};
-  if (tid < 48) bias_in = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
-
   bf16* const img = p.buf + (long)b * p.buf_is;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(8u * plane_b), 0x00020000);
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(24u * plane_b), 0x00020000);
@@ -157,50 +178,36 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
     const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
   }
-  // ---- weights: chunk n of the tile's 52 lives at n * WCHUNK_BYTES of the packed block
-  const unsigned woff0 = (unsigned)tid * 16u, woff1 = (unsigned)(256 + tid) * 16u;
-  const unsigned woff2 = tid < 64 ? (unsigned)(512 + tid) * 16u : OOB;
-  auto issue_w = [&](int n, int stage) {
-    u32x4_* st = smem + W_BASE + stage * WSTAGE;
-    const unsigned base = (unsigned)n * WCHUNK_BYTES;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st + wave_u * 64), 16, woff0 + base, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st + 256 + wave_u * 64), 16, woff1 + base, 0, 0, 0);
-    // the last 64 slots of a chunk are wave 0's; the other waves issue the same instruction with
-    // every lane out of range (so that each wave counts three per chunk) into a dump area
-    u32x4_* d2 = wave_u == 0 ? st + 512 : smem + DUMP_BASE;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)d2, 16, woff2 == OOB ? OOB : woff2 + base, 0, 0, 0);
+  // packed biases (the accumulators' initial values) -> LDS
+  if (tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+
+  // ---- weights: every wave multiplies all 32 output channels of a chunk, so every lane reads its own
+  // 16-byte fragment of each of the nine taps straight into registers (1 KB per wave instruction,
+  // served by the L1 after the first wave), one chunk ahead of the multiply.  Nothing but the
+  // activations lives in LDS, so no barrier is needed inside a layer.
+  const unsigned wlane = (unsigned)(hh * 32 + pl) * 16u;
+  constexpr int WDEPTH = 3;                  // chunks in flight ahead of the multiply (L2 latency under load: about 1 us)
+  u32x4_ wbuf[WDEPTH + 1][9];
+  auto load_w = [&](int n, u32x4_ (&dst)[9]) {
+#ifdef RDB_ABLATE_NO_WLOAD
+    if (n >= 1) return;                       // timing-only build: weight fragments are never refreshed
+#endif
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+      dst[tp] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)tp * 1024u, (unsigned)n * WCHUNK_BYTES, 0);
   };
-  issue_w(0, 0);
-  issue_w(1, 1);
-  if (tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = bias_in;
-  // the biases are the accumulators' initial values: written by wave 0, read by every wave before
-  // its first chunk step
+#pragma unroll
+  for (int n0 = 0; n0 < WDEPTH; ++n0) load_w(n0, wbuf[n0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the input tile has landed (this wave's share) ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                             // ... and every other wave's, and the biases
+#ifdef RDB_ABLATE_EXIT_AFTER_STAGE
+  if (p.total > 0) return;                     // timing-only build: launch + input staging alone
+#endif
 
   const bf16x8* const lds = reinterpret_cast<const bf16x8*>(smem);
   bf16x8* const ldsw = reinterpret_cast<bf16x8*>(smem);
   const float* const lbias = reinterpret_cast<const float*>(smem + BIAS_BASE);
-
-  int n = 0, stage = 0;
-  int extra = 0;             // global stores this wave has issued since its last counted wait
-
-  // one chunk step of the ring: chunk n has landed in every wave, chunk n + 2 goes out
-  auto step_begin = [&]() {
-    if (n + 1 >= NCHUNK_TOTAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (extra == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (extra == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (extra == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    extra = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes of the previous layer
-    __builtin_amdgcn_s_barrier();
-    if (n + 2 < NCHUNK_TOTAL) issue_w(n + 2, stage >= 1 ? stage - 1 : NSTG - 1);
-  };
-  auto step_end = [&]() {
-    ++n;
-    stage = stage == NSTG - 1 ? 0 : stage + 1;
-  };
 
   static_for<5>([&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
@@ -217,8 +224,11 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
       py[rg] = pc / OWd;
       px[rg] = pc - py[rg] * OWd;
     }
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
+    static_for<NPASS>([&](auto Pc) {
+      constexpr int pass = decltype(Pc)::value;
+#ifdef RDB_ABLATE_LAYERS
+      if (L >= RDB_ABLATE_LAYERS) return;       // timing-only build: the first layers alone
+#endif
       f32x16 acc[RW];
       {
         const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + 32 * pass + hh * 16);
@@ -238,14 +248,18 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
         int ps[RW];
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg) ps[rg] = (py[rg] + O) * SW + px[rg] + O;
-        for (int cc = 0; cc < (S == 0 ? 4 : 2); ++cc) {
-          step_begin();
-          const bf16x8* sw = lds + W_BASE + stage * WSTAGE;
+        static_for<(S == 0 ? 4 : 2)>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          constexpr int n = chunk_index(L, pass, S, cc);
+          constexpr bool PF = n + WDEPTH < NCHUNK_TOTAL;
+          constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
+          const unsigned noff = (unsigned)(n + WDEPTH) * WCHUNK_BYTES;
           const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP;
-          if (RW == 1 || last_valid) chunk_mma<RW>(sw, sx, SW, ps, acc, pl, hh);
-          else chunk_mma<(RW > 1 ? RW - 1 : 1)>(sw, sx, SW, ps, acc, pl, hh);
-          step_end();
-        }
+          if (RW == 1 || last_valid)
+            chunk_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
+          else
+            chunk_mma<(RW > 1 ? RW - 1 : 1), PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
+        });
       });
 
       if constexpr (L < 4) {
@@ -275,7 +289,9 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
             }
           }
         }
-        if constexpr (STORE) extra = 2 * RW;
+        // the next layer reads what every wave has just written
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       } else {
         // conv5: alpha * y + beta1 * x + beta2 * res2 for the 32 channels of this pass
         const int gy = oy0 + py[0], gx = ox0 + px[0];
@@ -316,9 +332,8 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
           const unsigned off = in_img ? (unsigned)oct * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
         }
-        extra = 2;
       }
-    }
+    });
   });
 }
 
