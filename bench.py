@@ -562,7 +562,7 @@ def main():
         # under profiles/ with the command that produced it
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as f:
                 k = json.load(f)["kernels"].get(name)
             if k and not adv and (B, h, args.blocks) == (16, 64, 23):
                 traffic = k["fetch_bytes"] + k["write_bytes"]
@@ -570,7 +570,7 @@ def main():
             pass
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                           "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_traffic.json)",
+                           "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r3_pmc_traffic.json)",
                            "launches": n, "avg_us": round(ms * 1e3 / n, 2),
                            "share_of_step_kernel_time": round(ms / tot, 3)}
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0]

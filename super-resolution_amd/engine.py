@@ -653,9 +653,19 @@ class _GenBase(Plan):
         return self.packed_layer(wt.shape[0], wt.shape[1], 9, perm, [conv_seg(wt)],
                                  P[name + ".bias"].data_ptr(), dst_w=dst_w, dst_bias=dst_bias)
 
-    # One launch per dense block forward (csrc/rdb.hip) where the shape allows it: bf16, 64 block
-    # channels, 32 growth channels.  SRX_FUSED_RDB=0 keeps the five-launch form (A/B runs, tests).
-    fused_rdb = os.environ.get("SRX_FUSED_RDB", "1") != "0"
+    # One launch per dense block forward (csrc/rdb.hip) where the shape allows it (bf16, 64 block
+    # channels, 32 growth channels) and where it is the faster form: while its 16 x 8-pixel tiles
+    # fit the chip in one round (at most one workgroup per CU).  Measured per block, 16 images:
+    # 32 x 32 (128 tiles) 27.9 us fused against 34.8 us as five launches; 64 x 64 (512 tiles, two
+    # rounds) 63.7 against 53.8; 64 images of 128 x 128: 854 against 518.
+    # SRX_FUSED_RDB=0 / 1 forces the five-launch / the fused form (A/B runs, tests).
+    fused_rdb = {"0": False, "1": True}.get(os.environ.get("SRX_FUSED_RDB", "auto"))
+    fused_rdb_max_tiles = 256
+
+    def use_fused_rdb(self, B: int, h: int, w: int, nf: int, gc: int) -> bool:
+        if self.dt != L.BF16 or (nf, gc) != (64, 32) or self.fused_rdb is False:
+            return False
+        return bool(self.fused_rdb) or B * _ceil(h, 8) * _ceil(w, 16) <= self.fused_rdb_max_tiles
 
     def rdb_fwd(self, ops: list, cur: Buf, dst: View, w_ptr: int, bias_ptr: int, B: int, h: int, w: int,
                 nf: int, gc: int, store_growth: bool, alpha: float, beta1: float,
@@ -692,7 +702,7 @@ class _GenBase(Plan):
         """ResidualDenseBlock.forward (esrgan/generator.py:17-23); q == 2 also applies the
         enclosing RRDB's ``out*0.2 + x`` (:37) in the same epilogue."""
         nf8, gc8 = nf // 8, gc // 8
-        if self.fused_rdb and self.dt == L.BF16 and (nf, gc) == (64, 32):
+        if self.use_fused_rdb(B, h, w, nf, gc):
             # the five layers packed back to back: conv1..conv4 (4, 6, 8, 10 chunks of 9 x 512), conv5 (2 x 12)
             chunks = [(nf + k * gc) // 16 for k in range(4)] + [2 * (nf + 4 * gc) // 16]
             w_all = torch.empty(sum(chunks) * 9 * 512, dtype=self.tdtype, device=self.device)

@@ -15,13 +15,13 @@ def _plans(shape, need_grad, num_blocks=2):
     g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=51).cuda()
     params = {n: p.data for n, p in g.named_parameters()}
     B, h, w = shape
-    out = []
+    out, keep = [], E._GenBase.fused_rdb
     for fused in (False, True):
         E._GenBase.fused_rdb = fused
         try:
             out.append(E.GeneratorPlan(params, B, h, w, torch.bfloat16, num_blocks=num_blocks, need_grad=need_grad))
         finally:
-            E._GenBase.fused_rdb = True
+            E._GenBase.fused_rdb = keep
     names = [[m[0] for m in p.fwd_meta] for p in out]
     assert "rdb_fwd_kernel" not in names[0] and names[1].count("rdb_fwd_kernel") == 3 * num_blocks
     return out
@@ -71,3 +71,16 @@ def test_fused_block_rejects_what_it_does_not_cover():
     d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=32, gc=16)
     assert lib.srx_rdb_forward(d, None) == 1 and b"64 block channels" in lib.srx_last_error()
     assert lib.srx_rdb_forward(None, None) == 1
+
+
+def test_fused_block_is_chosen_by_size():
+    """Left to itself a plan takes the fused form while its tiles fit the chip in one round."""
+    E, G = pkg("engine"), pkg("esrgan.generator")
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=52).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    assert E._GenBase.fused_rdb is None
+    small = E.GeneratorPlan(params, 16, 32, 32, torch.bfloat16, num_blocks=1, need_grad=False)
+    large = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, num_blocks=1, need_grad=False)
+    f32 = E.GeneratorPlan(params, 2, 16, 16, torch.float32, num_blocks=1, need_grad=False)
+    assert [m[0] for m in small.fwd_meta].count("rdb_fwd_kernel") == 3
+    assert all(m[0] != "rdb_fwd_kernel" for m in large.fwd_meta + f32.fwd_meta)

@@ -35,7 +35,7 @@ def bench(B, H, W, blocks=6, reps=5, need_grad=1):
         fl = 2.0 * B * H * W * 239616
         print(f"B{B} {H}x{W} {'fused' if fused else 'five launches'}: {best:8.2f} us per block ({cnt} launches)  "
               f"{fl / best / 1e6:8.1f} TF/s", flush=True)
-    E._GenBase.fused_rdb = True
+    E._GenBase.fused_rdb = None
 
 
 for a in sys.argv[1:]:
