@@ -148,8 +148,23 @@ typedef struct srx_rdb_desc {
   float beta1;
   float beta2;
   const void* res2; int64_t res2_img_stride;   /* NULL: no second residual             */
+  const void* act;  int64_t act_img_stride;    /* srx_rdb_backward only: the block's buffer as the
+                                                * forward pass left it (x | x1..x4)      */
 } srx_rdb_desc;
 int srx_rdb_forward(const srx_rdb_desc* d, void* stream);
+/* The data gradient of the same block (autograd's backward of esrgan/generator.py:17-23 with
+ * respect to the activations) in ONE launch.  buf is the block's gradient buffer
+ * [gy1 | gy2 | gy3 | gy4 | g_out] (4 x gc/8 + nf/8 planes): planes [4 gc/8, ...) hold the gradient of
+ * the block output on entry; the kernel writes gy_j = LeakyReLU'(x_j) * (gradient reaching growth
+ * slice j) into the planes in front of them (the weight-gradient launches read them) and
+ *     y = (gradient reaching the block input through the five convolutions) + beta1 * g_out + beta2 * res2
+ * (beta1: the block's identity path; res2: the gradient of the enclosing RRDB's skip path).
+ * act: the block's activation buffer, whose growth slices give the derivative masks.  w: the five
+ * data-gradient layers (stacked, transposed, tap-flipped weights of convolutions j+1..5 for
+ * j = 4, 3, 2, 1, 0; the 0.2 of the residual scaling folded in) packed by srx_pack_weights back
+ * to back in that order (4, 6, 8, 10, 2 x 12 chunks); bias, alpha and store_growth are not used.
+ * Same results, bit for bit, as the five srx_conv2d calls it replaces. */
+int srx_rdb_backward(const srx_rdb_desc* d, void* stream);
 
 /* --------------------------------------------------------- weight gradients */
 /* One 64x64 (cin x cout) block task of a weight-gradient launch: four 32x32
@@ -388,6 +403,7 @@ int srx_crop_augment(const srx_crop* crops /*DEVICE*/, int B, int size, float* o
 #define SRX_OP_GAP_BWD 11
 #define SRX_OP_ACT_BWD 12
 #define SRX_OP_RDB_FWD 13
+#define SRX_OP_RDB_BWD 14
 
 typedef struct srx_generic_args {   /* for the bandwidth-bound helpers */
   int32_t dtype, B, C, H, W, noct;

@@ -23,6 +23,7 @@ OP_CONV, OP_WGRAD, OP_PIXEL_UNSHUFFLE, OP_CHANNEL_SUM, OP_ZERO_STUFF = 1, 2, 3, 
 OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_MEMSET, OP_AXPBY, OP_GAP_FWD, OP_GAP_BWD = 6, 7, 8, 9, 10, 11
 OP_ACT_BWD = 12
 OP_RDB_FWD = 13
+OP_RDB_BWD = 14
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -98,7 +99,7 @@ class RdbDesc(C.Structure):
                 ("store_growth", i32), ("pad_", i32),
                 ("buf", vp), ("buf_img_stride", i64), ("y", vp), ("y_img_stride", i64),
                 ("w", vp), ("bias", vp), ("act_slope", f32), ("alpha", f32), ("beta1", f32), ("beta2", f32),
-                ("res2", vp), ("res2_img_stride", i64)]
+                ("res2", vp), ("res2_img_stride", i64), ("act", vp), ("act_img_stride", i64)]
 
 
 class _OpU(C.Union):
@@ -122,6 +123,7 @@ _SIGS = {
     "srx_conv2d": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "srx_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
     "srx_rdb_forward": (C.c_int, [C.POINTER(RdbDesc), vp]),
+    "srx_rdb_backward": (C.c_int, [C.POINTER(RdbDesc), vp]),
     "srx_unpack_wgrad": (C.c_int, [vp, C.c_int, i64, vp]),
     "srx_channel_sum": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
     "srx_pixel_unshuffle2": (C.c_int, [C.c_int, vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -77,6 +77,7 @@ int srx_run_ops(const srx_op* ops, int n, void* stream) {
       case SRX_OP_CONV: rc = srx_conv2d(&op.u.conv, stream); break;
       case SRX_OP_WGRAD: rc = srx_conv2d_wgrad(&op.u.wgrad, stream); break;
       case SRX_OP_RDB_FWD: rc = srx_rdb_forward(&op.u.rdb, stream); break;
+      case SRX_OP_RDB_BWD: rc = srx_rdb_backward(&op.u.rdb, stream); break;
       case SRX_OP_PIXEL_UNSHUFFLE:
         rc = srx_pixel_unshuffle2(g.dtype, g.a, g.a_img_stride, g.c, g.c_img_stride, g.B, g.C, g.H, g.W, stream);
         break;

@@ -22,6 +22,15 @@
 // floating-point operation are those of conv_kernel (conv.hip), so the results equal the
 // layer-by-layer path bit for bit.
 //
+// The data gradient of a dense block has the same shape as its forward pass (BWD = true): with the
+// gradient buffer laid out [gy1 | gy2 | gy3 | gy4 | g_out], the gradient of growth slice j is one
+// convolution over the planes [gy_(j+1) .. g_out] with the stacked, transposed, tap-flipped
+// weights of convolutions j+1 .. 5, times LeakyReLU'(x_j).  Layer L of the kernel then computes
+// gy_(4-L) from g_out (source 0, staged with its 5-pixel halo) and the slices computed before it,
+// newest first (the channel order of the gradient buffer); the derivative masks come from the
+// block's activation buffer (a global read per lane and layer, issued in front of the K loop);
+// layer 4 gives the gradient of the block input, plus beta1 * g_out + beta2 * res2.
+//
 // bf16, 64 block channels, 32 growth channels only (what the reference instantiates,
 // esrgan/generator.py:8,27); other shapes take the layer-by-layer path.
 #include <stdlib.h>
@@ -47,7 +56,10 @@ constexpr int LDS_BYTES = LDS_SLOTS * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int X_SLOTS = src_planes(0) * reg_p(HALO);          // 3744
 constexpr int X_DMA = (X_SLOTS + 255) / 256;                   // staging instructions per wave for x
-constexpr int NCHUNK_TOTAL = 4 + 6 + 8 + 10 + 2 * 12;          // weight chunks per tile
+constexpr int NCHUNK_TOTAL = 4 + 6 + 8 + 10 + 2 * 12;          // weight chunks of a block
+// A wave multiplies the chunks of layers 0..3 and those of ONE 32-channel half of layer 4 (waves
+// split that layer 2 halves x 2 pixel-group pairs): 40 chunks stream through its registers.
+constexpr int NCHUNK_WAVE = 4 + 6 + 8 + 10 + 12;
 constexpr unsigned WCHUNK_BYTES = 9 * 512 * 2;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -55,16 +67,18 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int out_halo(int L) { return L < 4 ? HALO - 1 - L : 0; }
 constexpr int out_p(int L) { return reg_p(out_halo(L)); }
 constexpr int out_groups(int L) { return (out_p(L) + 31) / 32; }            // 12 10 8 6 4
-constexpr int rw_max(int L) { return (out_groups(L) + 3) / 4; }             // 3 3 2 2 1
+// layer 4: each wave takes two of the four groups for one 32-channel half of the output
+constexpr int rw_max(int L) { return L == 4 ? 2 : (out_groups(L) + 3) / 4; }   // 3 3 2 2 2
 // which waves take the odd groups alternates between the layers that have them
 constexpr int wave_rot(int L) { return L == 3 ? 2 : 0; }
 constexpr int bias_off(int L) { return 32 * L; }                            // floats; conv5: + 32 * pass
 
 struct RdbParams {
-  bf16* buf; long buf_is;           // block buffer, 24 octet planes per image
+  bf16* buf; long buf_is;           // block buffer (x | x1..x4) or gradient buffer (gy1..gy4 | g_out): 24 octet planes per image
   bf16* y; long y_is;               // output view, 8 planes
   const bf16* w; const float* bias;
   const bf16* res2; long r2_is;
+  const bf16* act; long act_is;     // BWD: the block's activation buffer (derivative masks)
   float slope, alpha, beta1, beta2;
   int H, W, tiles_x, tiles_y, total;
 };
@@ -129,18 +143,28 @@ __device__ __forceinline__ void chunk_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)
   }
 }
 
-// chunk index (0..51) of (layer, pass, source, chunk of the source) in the packed weight block
+// Position of a chunk in the stream of weight chunks a wave multiplies: (layer, source, chunk of
+// the source).  Forward: sources in the order block input, x1, x2, ...; backward: newest slice
+// first, g_out last (the channel order of each buffer, hence of the packed weights).
 constexpr int layer_chunk0(int L) { return L == 0 ? 0 : L == 1 ? 4 : L == 2 ? 10 : L == 3 ? 18 : 28; }
-constexpr int chunk_index(int L, int pass, int S, int cc) {
-  return layer_chunk0(L) + 12 * pass + (S == 0 ? 0 : 4 + 2 * (S - 1)) + cc;
+template <bool BWD> constexpr int src_at(int L, int i) { return BWD ? (i < L ? L - i : 0) : i; }
+template <bool BWD> constexpr int src_pos(int L, int S) {
+  return BWD ? (S == 0 ? 2 * L : 2 * (L - S)) : (S == 0 ? 0 : 4 + 2 * (S - 1));
 }
+template <bool BWD> constexpr int chunk_index(int L, int S, int cc) { return layer_chunk0(L) + src_pos<BWD>(L, S) + cc; }
+// planes (in buf) of the kernel's input and of the slice layer L produces; BWD: plane (in act) of its mask
+template <bool BWD> constexpr int in_plane0() { return BWD ? 16 : 0; }
+template <bool BWD> constexpr int slice_plane(int L) { return BWD ? 4 * (3 - L) : 8 + 4 * L; }
+constexpr int mask_plane(int L) { return 8 + 4 * (3 - L); }
 
-template <bool STORE>
-__global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
+template <bool BWD, bool STORE>
+__global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
   extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, pl = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // layer 4: this wave's 32-channel half of the output and its pair of pixel groups
+  const int pass5 = wave_u & 1, pair5 = wave_u >> 1;
 
   // workgroup -> tile, one contiguous run of tiles per XCD (neighbouring tiles share most of their
   // halo: they should meet in one XCD's L2)
@@ -157,17 +181,20 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
   const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
 
   bf16* const img = p.buf + (long)b * p.buf_is;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(8u * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      img + (long)in_plane0<BWD>() * H * W * 8, 0, (int)(8u * plane_b), 0x00020000);
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(24u * plane_b), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.y_is, 0, (int)(8u * plane_b), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)(NCHUNK_TOTAL * WCHUNK_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(BWD ? p.act + (long)b * p.act_is : p.w), 0, (int)(BWD ? 24u * plane_b : 0u), 0x00020000);
 
-  // ---- the block input over the tile + 5-pixel halo: X_DMA LDS-DMA instructions per wave; pixels
-  // outside the image (the zero padding) and the slots past the region get an out-of-range offset,
-  // for which the hardware deposits zeros (the few slots past the region belong to growth slice 1,
-  // which is written later)
+  // ---- the kernel's input (block input / g_out) over the tile + 5-pixel halo: X_DMA LDS-DMA
+  // instructions per wave; pixels outside the image (the zero padding) and the slots past the region
+  // get an out-of-range offset, for which the hardware deposits zeros (the few slots past the region
+  // belong to the first slice, which is written later)
 #pragma unroll
   for (int j = 0; j < X_DMA; ++j) {
     const unsigned slot = (unsigned)(j * 256 + tid);
@@ -178,23 +205,27 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
     const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
   }
-  // packed biases (the accumulators' initial values) -> LDS
-  if (tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+  // packed biases (the accumulators' initial values) -> LDS; the data gradient has none
+  if (!BWD && tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
 
   // ---- weights: every wave multiplies all 32 output channels of a chunk, so every lane reads its own
   // 16-byte fragment of each of the nine taps straight into registers (1 KB per wave instruction,
-  // served by the L1 after the first wave), one chunk ahead of the multiply.  Nothing but the
-  // activations lives in LDS, so no barrier is needed inside a layer.
+  // served by the L1 after the first wave), WDEPTH chunks ahead of the multiply.  Nothing but the
+  // activations lives in LDS, so no barrier is needed inside a layer.  Position n of a wave's chunk
+  // stream is chunk n of the packed block for layers 0..3 and chunk n + 12 * (its half) for layer 4.
   const unsigned wlane = (unsigned)(hh * 32 + pl) * 16u;
   constexpr int WDEPTH = 3;                  // chunks in flight ahead of the multiply (L2 latency under load: about 1 us)
   u32x4_ wbuf[WDEPTH + 1][9];
+  auto chunk_bytes = [&](int n) -> unsigned {          // n: compile-time after unrolling
+    return n < layer_chunk0(4) ? (unsigned)n * WCHUNK_BYTES : (unsigned)(n + 12 * pass5) * WCHUNK_BYTES;
+  };
   auto load_w = [&](int n, u32x4_ (&dst)[9]) {
 #ifdef RDB_ABLATE_NO_WLOAD
     if (n >= 1) return;                       // timing-only build: weight fragments are never refreshed
 #endif
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
-      dst[tp] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)tp * 1024u, (unsigned)n * WCHUNK_BYTES, 0);
+      dst[tp] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)tp * 1024u, chunk_bytes(n), 0);
   };
 #pragma unroll
   for (int n0 = 0; n0 < WDEPTH; ++n0) load_w(n0, wbuf[n0]);
@@ -212,166 +243,199 @@ __global__ __launch_bounds__(256, 1) void rdb_fwd_kernel(const RdbParams p) {
   static_for<5>([&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
     constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
-    constexpr int NPASS = L == 4 ? 2 : 1;
-    // this wave's pixel groups: g = rg * 4 + ((wave + rot) & 3); only the last rg can be missing
+#ifdef RDB_ABLATE_LAYERS
+    if (L >= RDB_ABLATE_LAYERS) return;         // timing-only build: the first layers alone
+#endif
+    // this wave's pixel groups.  Layers 0..3: g = rg * 4 + ((wave + rot) & 3), only the last rg can be
+    // missing; layer 4: the pair of groups 2 * pair5 + rg.
     const int wsel = (wave_u + wave_rot(L)) & 3;
-    const bool last_valid = (RW - 1) * 4 + wsel < NG;                  // wave-uniform
+    const bool last_valid = L == 4 || (RW - 1) * 4 + wsel < NG;          // wave-uniform
     int py[RW], px[RW], pp[RW];
 #pragma unroll
     for (int rg = 0; rg < RW; ++rg) {
-      pp[rg] = (rg * 4 + wsel) * 32 + pl;
+      pp[rg] = (L == 4 ? 2 * pair5 + rg : rg * 4 + wsel) * 32 + pl;
       const int pc = pp[rg] < OP ? pp[rg] : OP - 1;
       py[rg] = pc / OWd;
       px[rg] = pc - py[rg] * OWd;
     }
-    static_for<NPASS>([&](auto Pc) {
-      constexpr int pass = decltype(Pc)::value;
-#ifdef RDB_ABLATE_LAYERS
-      if (L >= RDB_ABLATE_LAYERS) return;       // timing-only build: the first layers alone
-#endif
-      f32x16 acc[RW];
-      {
-        const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + 32 * pass + hh * 16);
-        const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
+    // BWD: LeakyReLU'(x_j) of this wave's pixels, read from the activation buffer in front of the K
+    // loop (two octets per lane and group); pixels outside the image read zeros and are zeroed anyway
+    [[maybe_unused]] u32x4_ mk[RW][2];
+    if constexpr (BWD && L < 4) {
 #pragma unroll
-        for (int rg = 0; rg < RW; ++rg)
+      for (int rg = 0; rg < RW; ++rg) {
+        const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
+        const bool ok = (rg < RW - 1 || last_valid) && pp[rg] < OP && ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
-          }
+        for (int j = 0; j < 2; ++j)
+          mk[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
+              arsrc, ok ? (unsigned)(mask_plane(L) + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
       }
-      // K loop: sources in channel order (block input, then the growth slices), 16 channels a step
-      static_for<L + 1>([&](auto Sc) {
-        constexpr int S = decltype(Sc)::value;
-        constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
-        constexpr int O = L - S;                     // offset of this layer's region inside the source's, minus the tap pad
-        int ps[RW];
-#pragma unroll
-        for (int rg = 0; rg < RW; ++rg) ps[rg] = (py[rg] + O) * SW + px[rg] + O;
-        static_for<(S == 0 ? 4 : 2)>([&](auto Cc) {
-          constexpr int cc = decltype(Cc)::value;
-          constexpr int n = chunk_index(L, pass, S, cc);
-          constexpr bool PF = n + WDEPTH < NCHUNK_TOTAL;
-          constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
-          const unsigned noff = (unsigned)(n + WDEPTH) * WCHUNK_BYTES;
-          const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP;
-          if (RW == 1 || last_valid)
-            chunk_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
-          else
-            chunk_mma<(RW > 1 ? RW - 1 : 1), PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
-        });
-      });
+    }
 
-      if constexpr (L < 4) {
-        // bias is in the accumulators; LeakyReLU; zero outside the image (the next layer's padding);
-        // into LDS for the layers behind, and the tile's own pixels to the block buffer
+    f32x16 acc[RW];
+    if constexpr (BWD) {
 #pragma unroll
-        for (int rg = 0; rg < RW; ++rg) {
-          const bool has = rg < RW - 1 || last_valid;                 // wave-uniform
-          const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
-          const bool lane_ok = has && pp[rg] < OP;
-          const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-          const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
+      for (int rg = 0; rg < RW; ++rg)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            bf16x8 o;
+        for (int i = 0; i < 16; ++i) acc[rg][i] = 0.f;
+    } else {
+      const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + (L == 4 ? 32 * pass5 : 0) + hh * 16);
+      const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float v = acc[rg][j * 8 + e];
-              v = fmaxf(v, v * p.slope);
-              o[e] = (bf16)(in_img ? v : 0.f);
-            }
-            const int oct = 2 * j + hh;
-            if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
-            if constexpr (STORE) {
-              const unsigned off = own ? (unsigned)(8 + 4 * L + oct) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), grsrc, off, 0, 0);
-            }
+      for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
+        }
+    }
+    // K loop: sources in the channel order of the buffer, 16 channels a step
+    static_for<L + 1>([&](auto Ic) {
+      constexpr int S = src_at<BWD>(L, decltype(Ic)::value);
+      constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
+      constexpr int O = L - S;                     // offset of this layer's region inside the source's, minus the tap pad
+      int ps[RW];
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg) ps[rg] = (py[rg] + O) * SW + px[rg] + O;
+      static_for<(S == 0 ? 4 : 2)>([&](auto Cc) {
+        constexpr int cc = decltype(Cc)::value;
+        constexpr int n = chunk_index<BWD>(L, S, cc);
+        constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
+        constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
+        const unsigned noff = chunk_bytes(n + WDEPTH);
+        const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP;
+        if (RW == 1 || last_valid)
+          chunk_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
+        else
+          chunk_mma<(RW > 1 ? RW - 1 : 1), PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
+      });
+    });
+
+    if constexpr (L < 4) {
+      // forward: bias is in the accumulators, LeakyReLU; backward: times LeakyReLU'(x_j).  Zero outside
+      // the image (the next layer's padding); into LDS for the layers behind, and the tile's own
+      // pixels to the buffer (the backward pass / the weight gradients read them)
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg) {
+        const bool has = rg < RW - 1 || last_valid;                 // wave-uniform
+        const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
+        const bool lane_ok = has && pp[rg] < OP;
+        const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 o;
+          [[maybe_unused]] bf16x8 m;
+          if constexpr (BWD) m = __builtin_bit_cast(bf16x8, mk[rg][j]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = acc[rg][j * 8 + e];
+            if constexpr (BWD) v = (float)m[e] > 0.f ? v : v * p.slope;
+            else v = fmaxf(v, v * p.slope);
+            o[e] = (bf16)(in_img ? v : 0.f);
+          }
+          const int oct = 2 * j + hh;
+          if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
+          if constexpr (STORE) {
+            const unsigned off = own ? (unsigned)(slice_plane<BWD>(L) + oct) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), grsrc, off, 0, 0);
           }
         }
-        // the next layer reads what every wave has just written
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      } else {
-        // conv5: alpha * y + beta1 * x + beta2 * res2 for the 32 channels of this pass
-        const int gy = oy0 + py[0], gx = ox0 + px[0];
+      }
+      // the next layer reads what every wave has just written
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      // last layer: alpha * y + beta1 * (the kernel's input) + beta2 * res2 for this wave's 32 channels
+#pragma unroll
+      for (int rg = 0; rg < RW; ++rg) {
+        const int gy = oy0 + py[rg], gx = ox0 + px[rg];
         const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-        const int xs = (py[0] + HALO) * reg_w(HALO) + px[0] + HALO;
+        const int xs = (py[rg] + HALO) * reg_w(HALO) + px[rg] + HALO;
         bf16x8 r2[2];
         if (p.res2 != nullptr) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int oct = pass * 4 + 2 * j + hh;
+            const int oct = pass5 * 4 + 2 * j + hh;
             if (in_img)
               r2[j] = *reinterpret_cast<const bf16x8*>(p.res2 + (long)b * p.r2_is + (long)oct * ((long)H * W * 8) +
                                                        ((long)gy * W + gx) * 8);
           }
         }
-        if (p.alpha != 1.f) acc[0] *= p.alpha;
+        if (p.alpha != 1.f) acc[rg] *= p.alpha;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int oct = pass * 4 + 2 * j + hh;
+          const int oct = pass5 * 4 + 2 * j + hh;
           const bf16x8 xr = lds[src_base(0) + oct * reg_p(HALO) + xs];
           const float b1 = p.beta1;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[0][j * 8 + e] += b1 * (float)xr[e];
+          for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b1 * (float)xr[e];
         }
         if (p.res2 != nullptr) {
           const float b2 = p.beta2;
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[0][j * 8 + e] += b2 * (float)r2[j][e];
+            for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b2 * (float)r2[j][e];
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int oct = pass * 4 + 2 * j + hh;
+          const int oct = pass5 * 4 + 2 * j + hh;
           bf16x8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[0][j * 8 + e];
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[rg][j * 8 + e];
           const unsigned off = in_img ? (unsigned)oct * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
         }
       }
-    });
+    }
   });
 }
 
 }  // namespace
 
-extern "C" int srx_rdb_forward(const srx_rdb_desc* d, void* stream) {
-  SRX_CHECK_ARG(d != nullptr, "srx_rdb_forward: null descriptor");
-  SRX_CHECK_ARG(d->dtype == SRX_BF16, "srx_rdb_forward: bf16 only (got dtype %d)", d->dtype);
-  SRX_CHECK_ARG(d->nf == 64 && d->gc == 32, "srx_rdb_forward: 64 block channels and 32 growth channels only (got %d, %d)",
+static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char* who) {
+  SRX_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  SRX_CHECK_ARG(d->dtype == SRX_BF16, "%s: bf16 only (got dtype %d)", who, d->dtype);
+  SRX_CHECK_ARG(d->nf == 64 && d->gc == 32, "%s: 64 block channels and 32 growth channels only (got %d, %d)", who,
                 d->nf, d->gc);
-  SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0, "srx_rdb_forward: non-positive size");
-  SRX_CHECK_ARG(d->buf && d->y && d->w && d->bias, "srx_rdb_forward: null buf / y / w / bias pointer");
-  SRX_CHECK_ARG(((uintptr_t)d->buf | (uintptr_t)d->y | (uintptr_t)d->w | (uintptr_t)d->bias | (uintptr_t)d->res2) % 16 == 0,
-                "srx_rdb_forward: pointers must be 16-byte aligned");
+  SRX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0, "%s: non-positive size", who);
+  SRX_CHECK_ARG(d->buf && d->y && d->w && (bwd ? d->act != nullptr : d->bias != nullptr),
+                "%s: null buf / y / w / %s pointer", who, bwd ? "act" : "bias");
+  SRX_CHECK_ARG(((uintptr_t)d->buf | (uintptr_t)d->y | (uintptr_t)d->w | (uintptr_t)d->bias | (uintptr_t)d->res2 |
+                 (uintptr_t)d->act) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
   // one image's 24 planes are addressed through a 32-bit buffer descriptor
-  SRX_CHECK_ARG((long)d->H * d->W * 16 * 24 < 0x7FFFFFF0L, "srx_rdb_forward: image of %d x %d is too large for one launch; "
-                "tile the image", d->H, d->W);
+  SRX_CHECK_ARG((long)d->H * d->W * 16 * 24 < 0x7FFFFFF0L, "%s: image of %d x %d is too large for one launch; "
+                "tile the image", who, d->H, d->W);
   RdbParams p;
   p.buf = static_cast<bf16*>(d->buf); p.buf_is = d->buf_img_stride;
   p.y = static_cast<bf16*>(d->y); p.y_is = d->y_img_stride;
   p.w = static_cast<const bf16*>(d->w); p.bias = d->bias;
   p.res2 = static_cast<const bf16*>(d->res2); p.r2_is = d->res2_img_stride;
+  p.act = static_cast<const bf16*>(d->act); p.act_is = d->act_img_stride;
   p.slope = d->act_slope; p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2;
   p.H = d->H; p.W = d->W;
   p.tiles_x = (d->W + TW - 1) / TW;
   p.tiles_y = (d->H + TH - 1) / TH;
   const long total = (long)p.tiles_x * p.tiles_y * d->B;
-  SRX_CHECK_ARG(total < (1L << 31), "srx_rdb_forward: grid out of range");
+  SRX_CHECK_ARG(total < (1L << 31), "%s: grid out of range", who);
   p.total = (int)total;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->store_growth) {
+  if (bwd) {
     static srx_per_device_once attr;
-    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_fwd_kernel<true>), LDS_BYTES)) return rc;
-    hipLaunchKernelGGL(rdb_fwd_kernel<true>, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<true, true>), LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((rdb_kernel<true, true>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+  } else if (d->store_growth) {
+    static srx_per_device_once attr;
+    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<false, true>), LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((rdb_kernel<false, true>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
   } else {
     static srx_per_device_once attr;
-    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_fwd_kernel<false>), LDS_BYTES)) return rc;
-    hipLaunchKernelGGL(rdb_fwd_kernel<false>, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<false, false>), LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((rdb_kernel<false, false>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
   }
-  return srx_check_launch("rdb_fwd_kernel");
+  return srx_check_launch(bwd ? "rdb_kernel (backward)" : "rdb_kernel (forward)");
 }
+
+extern "C" int srx_rdb_forward(const srx_rdb_desc* d, void* stream) { return rdb_launch(d, stream, false, "srx_rdb_forward"); }
+extern "C" int srx_rdb_backward(const srx_rdb_desc* d, void* stream) { return rdb_launch(d, stream, true, "srx_rdb_backward"); }

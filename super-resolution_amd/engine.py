@@ -667,24 +667,39 @@ class _GenBase(Plan):
             return False
         return bool(self.fused_rdb) or B * _ceil(h, 8) * _ceil(w, 16) <= self.fused_rdb_max_tiles
 
+    # The same for the data gradient of a dense block (srx_rdb_backward).  Beside it the weight
+    # gradients of the side stream find no room on a CU it occupies (132 KB of LDS): only where its
+    # tiles leave CUs free.  SRX_FUSED_RDB_BWD=0 / 1 forces the choice.
+    fused_rdb_bwd = {"0": False, "1": True}.get(os.environ.get("SRX_FUSED_RDB_BWD", "auto"))
+    fused_rdb_bwd_max_tiles = 256
+
+    def use_fused_rdb_bwd(self, B: int, h: int, w: int, nf: int, gc: int) -> bool:
+        if self.dt != L.BF16 or (nf, gc) != (64, 32) or self.fused_rdb_bwd is False:
+            return False
+        return bool(self.fused_rdb_bwd) or B * _ceil(h, 8) * _ceil(w, 16) <= self.fused_rdb_bwd_max_tiles
+
     def rdb_fwd(self, ops: list, cur: Buf, dst: View, w_ptr: int, bias_ptr: int, B: int, h: int, w: int,
                 nf: int, gc: int, store_growth: bool, alpha: float, beta1: float,
-                res2: Optional[View] = None, beta2: float = 0.0):
+                res2: Optional[View] = None, beta2: float = 0.0, backward_of: Optional[Buf] = None):
+        """One-launch dense block: forward over the block buffer `cur`, or (backward_of = the block's
+        activation buffer) its data gradient over the gradient buffer `cur`."""
         op = L.Op()
-        op.kind = L.OP_RDB_FWD
+        op.kind = L.OP_RDB_FWD if backward_of is None else L.OP_RDB_BWD
         d = op.u.rdb
         d.dtype, d.B, d.H, d.W, d.nf, d.gc = self.dt, B, h, w, nf, gc
         d.store_growth = 1 if store_growth else 0
         d.buf, d.buf_img_stride = cur.ptr(0), cur.img_stride
         d.y, d.y_img_stride = dst[0].ptr(dst[1]), dst[0].img_stride
-        d.w, d.bias = w_ptr, bias_ptr
+        d.w, d.bias = w_ptr, bias_ptr or None
         d.act_slope, d.alpha, d.beta1, d.beta2 = LRELU, alpha, beta1, beta2
         if res2 is not None:
             d.res2, d.res2_img_stride = res2[0].ptr(res2[1]), res2[0].img_stride
+        if backward_of is not None:
+            d.act, d.act_img_stride = backward_of.ptr(0), backward_of.img_stride
         ops.append(op)
         if isinstance(ops, OpList):
             macs = sum(9 * (nf + k * gc) * gc for k in range(4)) + 9 * (nf + 4 * gc) * nf
-            ops.meta.append(("rdb_fwd_kernel", 2.0 * B * h * w * macs))
+            ops.meta.append(("rdb_fwd_kernel" if backward_of is None else "rdb_bwd_kernel", 2.0 * B * h * w * macs))
 
     def dgrad_layer(self, P, name, cout_v):
         wt = P[name + ".weight"]
@@ -750,8 +765,29 @@ class _GenBase(Plan):
             for k in range(j + 1, 6):
                 segs.append(dgrad_seg(W[k - 1], c0, src_off, s5 if k == 5 else 1.0))
                 c0 += W[k - 1].shape[0]
-            dg[j] = (self.packed_layer(nf if j == 0 else gc, c0, 9, 0, segs, with_bias=False)[0], c0)
-        for j in range(4, -1, -1):
+            dg[j] = (segs, c0)
+        fused = self.use_fused_rdb_bwd(B, h, w, nf, gc)
+        if fused:
+            # the five data-gradient layers packed back to back, j = 4 .. 0 (4, 6, 8, 10, 2 x 12 chunks)
+            chunks = [_ceil(dg[j][1], 16) * (1 if j else nf // 32) for j in range(4, -1, -1)]
+            w_all = torch.empty(sum(chunks) * 9 * 512, dtype=self.tdtype, device=self.device)
+            self.keep.append(w_all)
+            self.bytes_alloc += w_all.numel() * self.esize
+            wo = 0
+            for j, nch in zip(range(4, -1, -1), chunks):
+                self.packed_layer(nf if j == 0 else gc, dg[j][1], 9, 0, dg[j][0], with_bias=False,
+                                  dst_w=w_all[wo:wo + nch * 9 * 512])
+                wo += nch * 9 * 512
+            if q == 0 and rrdb_g is not None:
+                self.rdb_fwd(ops, G, dst, w_all.data_ptr(), 0, B, h, w, nf, gc, True, 1.0, 1.0, rrdb_g, 1.0,
+                             backward_of=cur)
+            else:
+                self.rdb_fwd(ops, G, dst, w_all.data_ptr(), 0, B, h, w, nf, gc, True, 1.0,
+                             RES if q == 2 else 1.0, backward_of=cur)
+        else:
+            for j in dg:
+                dg[j] = (self.packed_layer(nf if j == 0 else gc, dg[j][1], 9, 0, dg[j][0], with_bias=False)[0], dg[j][1])
+        for j in range(4, -1, -1) if not fused else ():
             wp, c0 = dg[j]
             xin = (G, j * gc8)
             if j > 0:

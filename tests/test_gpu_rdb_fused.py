@@ -1,7 +1,8 @@
-"""The fused dense-block forward (srx_rdb_forward, one launch per ResidualDenseBlock) against the
-layer-by-layer path (five srx_conv2d launches): the same bits, for training plans (growth slices
-stored for the backward pass) and inference plans (only the block output written), on image
-sizes that are and are not multiples of the 16 x 8 tile, including images smaller than a tile."""
+"""The fused dense-block forward (srx_rdb_forward, one launch per ResidualDenseBlock) and the fused
+data gradient of the block (srx_rdb_backward) against the layer-by-layer path (five srx_conv2d
+launches each): the same bits, for training plans (growth slices stored for the backward pass) and
+inference plans (only the block output written), on image sizes that are and are not multiples of
+the 16 x 8 tile, including images smaller than a tile."""
 import pytest
 import torch
 
@@ -10,20 +11,25 @@ from helpers import O, fill_module_, pkg
 pytestmark = pytest.mark.gpu
 
 
-def _plans(shape, need_grad, num_blocks=2):
+def _plans(shape, need_grad, num_blocks=2, fused_bwd=False):
+    """(layer-by-layer plan, plan with the fused forward [and the fused data gradient])"""
     E, G = pkg("engine"), pkg("esrgan.generator")
     g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=51).cuda()
     params = {n: p.data for n, p in g.named_parameters()}
     B, h, w = shape
-    out, keep = [], E._GenBase.fused_rdb
+    out, keep = [], (E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd)
     for fused in (False, True):
-        E._GenBase.fused_rdb = fused
+        E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd = fused, fused and fused_bwd
         try:
             out.append(E.GeneratorPlan(params, B, h, w, torch.bfloat16, num_blocks=num_blocks, need_grad=need_grad))
         finally:
-            E._GenBase.fused_rdb = keep
+            E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd = keep
     names = [[m[0] for m in p.fwd_meta] for p in out]
     assert "rdb_fwd_kernel" not in names[0] and names[1].count("rdb_fwd_kernel") == 3 * num_blocks
+    if need_grad:
+        names = [[m[0] for m in p.bwd_meta] for p in out]
+        assert "rdb_bwd_kernel" not in names[0]
+        assert names[1].count("rdb_bwd_kernel") == (3 * num_blocks if fused_bwd else 0)
     return out
 
 
@@ -63,6 +69,29 @@ def test_fused_block_backward_uses_the_stored_growth_slices():
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
+def test_fused_block_data_gradient_equals_layer_by_layer(shape):
+    """srx_rdb_backward against the five data-gradient launches: every gradient buffer
+    (gy1..gy4 | g_out of every block) and the gradient reaching conv_first's output bit for bit;
+    the parameter gradients up to the summation order of the weight-gradient atomics."""
+    ref, fus = _plans(shape, True, fused_bwd=True)
+    B, h, w = shape
+    x = O.hash_input("fb.x", (B, 3, h, w)).cuda()
+    gy = O.hash_input("fb.gy", (B, 3, 4 * h, 4 * w)).cuda() / (B * 3 * 16 * h * w)
+    for p in (ref, fus):
+        p.forward(x)
+        p.backward(gy)
+    torch.cuda.synchronize()
+    for r, (a, b) in enumerate(zip(ref.G, fus.G)):
+        va, vb = a.t.view(torch.int16), b.t.view(torch.int16)
+        assert float(a.t.float().abs().max()) > 0
+        assert torch.equal(va, vb), f"gradient buffer {r} differs"
+    assert torch.equal(ref.gfeat.t.view(torch.int16), fus.gfeat.t.view(torch.int16))
+    a, b = ref.flat_grad, fus.flat_grad
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
 def test_fused_block_rejects_what_it_does_not_cover():
     L = pkg("_lib")
     lib = L.lib()
@@ -71,6 +100,9 @@ def test_fused_block_rejects_what_it_does_not_cover():
     d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=32, gc=16)
     assert lib.srx_rdb_forward(d, None) == 1 and b"64 block channels" in lib.srx_last_error()
     assert lib.srx_rdb_forward(None, None) == 1
+    d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32)
+    assert lib.srx_rdb_backward(d, None) == 1 and b"null buf" in lib.srx_last_error()
+    assert lib.srx_rdb_backward(None, None) == 1
 
 
 def test_fused_block_is_chosen_by_size():
