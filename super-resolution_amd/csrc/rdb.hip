@@ -81,6 +81,9 @@ struct RdbParams {
   const bf16* act; long act_is;     // BWD: the block's activation buffer (derivative masks)
   float slope, alpha, beta1, beta2;
   int H, W, tiles_x, tiles_y, total;
+#ifdef RDB_STAMPS
+  unsigned long long* stamps;       // timing build: shader-clock stamps of workgroup 0 ([wave][16])
+#endif
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
@@ -97,49 +100,32 @@ __device__ __forceinline__ void mma16(const bf16x8& a, const bf16x8& b, f32x16& 
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// One 16-channel chunk of one layer for R pixel groups: A = the chunk's nine weight fragments (in
-// registers), B = the activation fragments at the nine tap shifts, read from the LDS-resident
-// regions one tap row ahead of the MFMAs (same order of accumulation as conv_kernel: tap rows,
-// taps, groups).
+// One tap row (three taps) of one 16-channel chunk for R pixel groups: A = the chunk's weight
+// fragments of that row (in registers), B = the activation fragments at the three tap shifts, read
+// from the LDS-resident regions one tap row ahead (the caller reads row r + 1, or the first row of
+// the next chunk, in front of this call).  Same order of accumulation as conv_kernel: tap rows,
+// taps, groups.
 template <int R, bool PREFETCH>
-__device__ __forceinline__ void chunk_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)[9], __amdgpu_buffer_rsrc_t wrsrc,
-                                          unsigned wlane, unsigned wnext_off, const bf16x8* __restrict__ sx, int ws,
-                                          const int* ps, f32x16* acc) {
-  bf16x8 xf[2][3][R];
-  auto read_row = [&](int dy, int buf) {
-#ifdef RDB_ABLATE_NO_XREAD
-    if (dy > 0) return;                       // timing-only build: one tap row of activation fragments per chunk
-#endif
+__device__ __forceinline__ void row_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)[9], __amdgpu_buffer_rsrc_t wrsrc,
+                                        unsigned wlane, unsigned wnext_off, int dy, const bf16x8 (&xf)[3][R], f32x16* acc) {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+  for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-      for (int rg = 0; rg < R; ++rg) xf[buf][dx][rg] = sx[ps[rg] + dy * ws + dx];
-  };
-  read_row(0, 0);
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    if (dy + 1 < 3) read_row(dy + 1, (dy + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-      for (int rg = 0; rg < R; ++rg) {
+    for (int rg = 0; rg < R; ++rg) {
 #ifdef RDB_ABLATE_NO_MMA
-        if (dy + dx > 0) { asm volatile("" :: "v"(xf[dy & 1][dx][rg]), "v"(wf[dy * 3 + dx])); continue; }   // timing-only build
+      if (dy + dx > 0) { asm volatile("" :: "v"(xf[dx][rg]), "v"(wf[dy * 3 + dx])); continue; }   // timing-only build
 #endif
-        mma16(__builtin_bit_cast(bf16x8, wf[dy * 3 + dx]), xf[dy & 1][dx][rg], acc[rg]);
-      }
-      // the weight fragment of the same tap of a later chunk, one load per tap: nine loads issued
-      // back to back by four waves at once queue up in the address unit (16 cycles each) and hold
-      // the instruction stream, and with it the MFMAs, for their whole length
-      if constexpr (PREFETCH) {
-#ifndef RDB_ABLATE_NO_WLOAD
-        wnext[dy * 3 + dx] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)(dy * 3 + dx) * 1024u, wnext_off, 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      mma16(__builtin_bit_cast(bf16x8, wf[dy * 3 + dx]), xf[dx][rg], acc[rg]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    // the weight fragment of the same tap of a later chunk, one load per tap: nine loads issued
+    // back to back by four waves at once queue up in the address unit (16 cycles each) and hold
+    // the instruction stream, and with it the MFMAs, for their whole length
+    if constexpr (PREFETCH) {
+#ifndef RDB_ABLATE_NO_WLOAD
+      wnext[dy * 3 + dx] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)(dy * 3 + dx) * 1024u, wnext_off, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -147,11 +133,10 @@ __device__ __forceinline__ void chunk_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)
 // the source).  Forward: sources in the order block input, x1, x2, ...; backward: newest slice
 // first, g_out last (the channel order of each buffer, hence of the packed weights).
 constexpr int layer_chunk0(int L) { return L == 0 ? 0 : L == 1 ? 4 : L == 2 ? 10 : L == 3 ? 18 : 28; }
-template <bool BWD> constexpr int src_at(int L, int i) { return BWD ? (i < L ? L - i : 0) : i; }
-template <bool BWD> constexpr int src_pos(int L, int S) {
-  return BWD ? (S == 0 ? 2 * L : 2 * (L - S)) : (S == 0 ? 0 : 4 + 2 * (S - 1));
-}
-template <bool BWD> constexpr int chunk_index(int L, int S, int cc) { return layer_chunk0(L) + src_pos<BWD>(L, S) + cc; }
+// chunk i (0 .. 4 + 2 L - 1) of layer L: its source and its index inside the source
+constexpr int layer_nchunks(int L) { return 4 + 2 * L; }
+template <bool BWD> constexpr int chunk_src(int L, int i) { return BWD ? (i < 2 * L ? L - i / 2 : 0) : (i < 4 ? 0 : 1 + (i - 4) / 2); }
+template <bool BWD> constexpr int chunk_cc(int L, int i) { return BWD ? (i < 2 * L ? i % 2 : i - 2 * L) : (i < 4 ? i : (i - 4) % 2); }
 // planes (in buf) of the kernel's input and of the slice layer L produces; BWD: plane (in act) of its mask
 template <bool BWD> constexpr int in_plane0() { return BWD ? 16 : 0; }
 template <bool BWD> constexpr int slice_plane(int L) { return BWD ? 4 * (3 - L) : 8 + 4 * L; }
@@ -165,6 +150,17 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   // layer 4: this wave's 32-channel half of the output and its pair of pixel groups
   const int pass5 = wave_u & 1, pair5 = wave_u >> 1;
+#ifdef RDB_STAMPS
+  int stamp_k = 0;
+  auto stamp = [&]() {
+    const unsigned long long tnow = __builtin_readcyclecounter();
+    if (blockIdx.x == 8 && lane == 0 && p.stamps) p.stamps[wave_u * 16 + stamp_k] = tnow;
+    ++stamp_k;
+  };
+  stamp();
+#else
+  auto stamp = [] {};
+#endif
 
   // workgroup -> tile, one contiguous run of tiles per XCD (neighbouring tiles share most of their
   // halo: they should meet in one XCD's L2)
@@ -232,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the input tile has landed (this wave's share) ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                             // ... and every other wave's, and the biases
+  stamp();
 #ifdef RDB_ABLATE_EXIT_AFTER_STAGE
   if (p.total > 0) return;                     // timing-only build: launch + input staging alone
 #endif
@@ -247,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
     if (L >= RDB_ABLATE_LAYERS) return;         // timing-only build: the first layers alone
 #endif
     // this wave's pixel groups.  Layers 0..3: g = rg * 4 + ((wave + rot) & 3), only the last rg can be
-    // missing; layer 4: the pair of groups 2 * pair5 + rg.
+    // missing (the wave then multiplies a dummy group whose results are dropped: the waves that have
+    // the group set the layer's length anyway); layer 4: the pair of groups 2 * pair5 + rg.
     const int wsel = (wave_u + wave_rot(L)) & 3;
     const bool last_valid = L == 4 || (RW - 1) * 4 + wsel < NG;          // wave-uniform
     int py[RW], px[RW], pp[RW];
@@ -273,6 +271,24 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
       }
     }
 
+    // last layer: the second residual of this wave's pixels, likewise read in front of the K loop
+    [[maybe_unused]] u32x4_ r2w[RW][2];
+    if constexpr (L == 4) {
+      if (p.res2 != nullptr) {
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16*>(p.res2 + (long)b * p.r2_is), 0, (int)(8u * plane_b), 0x00020000);
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) {
+          const int gy = oy0 + py[rg], gx = ox0 + px[rg];
+          const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            r2w[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                rrsrc, in_img ? (unsigned)(pass5 * 4 + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
+        }
+      }
+    }
+
     f32x16 acc[RW];
     if constexpr (BWD) {
 #pragma unroll
@@ -289,28 +305,47 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
           acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
         }
     }
-    // K loop: sources in the channel order of the buffer, 16 channels a step
-    static_for<L + 1>([&](auto Ic) {
-      constexpr int S = src_at<BWD>(L, decltype(Ic)::value);
-      constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
-      constexpr int O = L - S;                     // offset of this layer's region inside the source's, minus the tap pad
-      int ps[RW];
+    // K loop: 16 channels a step, sources in the channel order of the buffer.  The activation
+    // fragments of a tap row are read while the row before it is multiplied, across chunk boundaries
+    // too: with one wave per SIMD nothing else hides the LDS latency.
+    constexpr int NC = layer_nchunks(L);
+    int ps[L + 1][RW];                              // per source: this lane's pixel at tap (0, 0)
+    static_for<L + 1>([&](auto Sc) {
+      constexpr int S = decltype(Sc)::value;
+      constexpr int SW = reg_w(src_halo(S)), O = L - S;   // O: offset of this layer's region inside the source's, minus the tap pad
 #pragma unroll
-      for (int rg = 0; rg < RW; ++rg) ps[rg] = (py[rg] + O) * SW + px[rg] + O;
-      static_for<(S == 0 ? 4 : 2)>([&](auto Cc) {
-        constexpr int cc = decltype(Cc)::value;
-        constexpr int n = chunk_index<BWD>(L, S, cc);
-        constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
-        constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
-        const unsigned noff = chunk_bytes(n + WDEPTH);
-        const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP;
-        if (RW == 1 || last_valid)
-          chunk_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
-        else
-          chunk_mma<(RW > 1 ? RW - 1 : 1), PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, sx, SW, ps, acc);
-      });
+      for (int rg = 0; rg < RW; ++rg) ps[S][rg] = (py[rg] + O) * SW + px[rg] + O;
+    });
+    bf16x8 xf[2][3][RW];
+    auto read_row = [&](auto Ic, int dy, bf16x8 (&dst)[3][RW]) {
+      constexpr int i = decltype(Ic)::value;
+      constexpr int S = chunk_src<BWD>(L, i), cc = chunk_cc<BWD>(L, i);
+      constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
+      const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) dst[dx][rg] = sx[ps[S][rg] + dx];
+    };
+    read_row(std::integral_constant<int, 0>{}, 0, xf[0]);
+    static_for<NC>([&](auto Ic) {
+      constexpr int i = decltype(Ic)::value;
+      constexpr int n = layer_chunk0(L) + i;
+      constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
+      constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
+      const unsigned noff = chunk_bytes(n + WDEPTH);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int cur = (3 * i + dy) & 1;
+        if (dy < 2) read_row(Ic, dy + 1, xf[cur ^ 1]);
+        else if constexpr (i + 1 < NC) read_row(std::integral_constant<int, i + 1>{}, 0, xf[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
 
+    stamp();
     if constexpr (L < 4) {
       // forward: bias is in the accumulators, LeakyReLU; backward: times LeakyReLU'(x_j).  Zero outside
       // the image (the next layer's padding); into LDS for the layers behind, and the tile's own
@@ -324,15 +359,33 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
         const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          // (this tail is straight VALU work in front of a barrier: instruction count is its price.
+          //  The maximum is taken by v_max_f32 itself: fmaxf() first quiets signalling NaNs with a
+          //  second v_max per value; the mask's sign is tested on the bf16 bit patterns; pixels
+          //  outside the image are zeroed on the packed words)
           bf16x8 o;
-          [[maybe_unused]] bf16x8 m;
-          if constexpr (BWD) m = __builtin_bit_cast(bf16x8, mk[rg][j]);
+          if constexpr (BWD) {
+            const u32x4_ mw = mk[rg][j];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = acc[rg][j * 8 + e];
-            if constexpr (BWD) v = (float)m[e] > 0.f ? v : v * p.slope;
-            else v = fmaxf(v, v * p.slope);
-            o[e] = (bf16)(in_img ? v : 0.f);
+            for (int e = 0; e < 8; ++e) {
+              const float v = acc[rg][j * 8 + e];
+              const bool pos = (e & 1) ? (int)mw[e >> 1] > 0xFFFF : (short)(mw[e >> 1] & 0xFFFFu) > 0;
+              o[e] = (bf16)(pos ? v : v * p.slope);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = acc[rg][j * 8 + e], t = v * p.slope;
+              float r;
+              asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+              o[e] = (bf16)r;
+            }
+          }
+          {
+            u32x4_ ow = __builtin_bit_cast(u32x4_, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ow[k] = in_img ? ow[k] : 0u;
+            o = __builtin_bit_cast(bf16x8, ow);
           }
           const int oct = 2 * j + hh;
           if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
@@ -345,6 +398,7 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
       // the next layer reads what every wave has just written
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      stamp();
     } else {
       // last layer: alpha * y + beta1 * (the kernel's input) + beta2 * res2 for this wave's 32 channels
 #pragma unroll
@@ -352,16 +406,6 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
         const int gy = oy0 + py[rg], gx = ox0 + px[rg];
         const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
         const int xs = (py[rg] + HALO) * reg_w(HALO) + px[rg] + HALO;
-        bf16x8 r2[2];
-        if (p.res2 != nullptr) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int oct = pass5 * 4 + 2 * j + hh;
-            if (in_img)
-              r2[j] = *reinterpret_cast<const bf16x8*>(p.res2 + (long)b * p.r2_is + (long)oct * ((long)H * W * 8) +
-                                                       ((long)gy * W + gx) * 8);
-          }
-        }
         if (p.alpha != 1.f) acc[rg] *= p.alpha;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -374,9 +418,11 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
         if (p.res2 != nullptr) {
           const float b2 = p.beta2;
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
+            const bf16x8 r2 = __builtin_bit_cast(bf16x8, r2w[rg][j]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b2 * (float)r2[j][e];
+            for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b2 * (float)r2[e];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -388,11 +434,17 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
         }
       }
+      stamp();
     }
   });
 }
 
 }  // namespace
+
+#ifdef RDB_STAMPS
+static unsigned long long* g_rdb_stamps = nullptr;
+extern "C" void srx_rdb_debug_stamps(void* buf) { g_rdb_stamps = static_cast<unsigned long long*>(buf); }
+#endif
 
 static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char* who) {
   SRX_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
@@ -420,6 +472,9 @@ static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char*
   const long total = (long)p.tiles_x * p.tiles_y * d->B;
   SRX_CHECK_ARG(total < (1L << 31), "%s: grid out of range", who);
   p.total = (int)total;
+#ifdef RDB_STAMPS
+  p.stamps = g_rdb_stamps;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (bwd) {
     static srx_per_device_once attr;
