@@ -96,7 +96,7 @@ class Crop(C.Structure):
 
 class RdbDesc(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("nf", i32), ("gc", i32),
-                ("store_growth", i32), ("pad_", i32),
+                ("store_growth", i32), ("tile", i32),
                 ("buf", vp), ("buf_img_stride", i64), ("y", vp), ("y_img_stride", i64),
                 ("w", vp), ("bias", vp), ("act_slope", f32), ("alpha", f32), ("beta1", f32), ("beta2", f32),
                 ("res2", vp), ("res2_img_stride", i64), ("act", vp), ("act_img_stride", i64)]

@@ -39,36 +39,13 @@
 
 namespace {
 
-constexpr int TW = 16, TH = 8, HALO = 5;
-constexpr int reg_h(int halo) { return TH + 2 * halo; }
-constexpr int reg_w(int halo) { return TW + 2 * halo; }
-constexpr int reg_p(int halo) { return reg_h(halo) * reg_w(halo); }
-// source s of a layer's input: 0 = block input (8 octet planes, halo 5); s = 1..4 = growth slice s
-// (4 planes, halo 5 - s).  Regions are stored [plane][pixel of the region], 16-byte slots.
-constexpr int src_halo(int s) { return HALO - s; }
-constexpr int src_planes(int s) { return s == 0 ? 8 : 4; }
-constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * reg_p(src_halo(s - 1)); }
-constexpr int ACT_SLOTS = src_base(5);
-static_assert(ACT_SLOTS == 8192, "activation regions");
-constexpr int BIAS_BASE = ACT_SLOTS;              // packed biases: 4 x 32 + 64 floats = 48 slots
-constexpr int LDS_SLOTS = BIAS_BASE + 64;
-constexpr int LDS_BYTES = LDS_SLOTS * 16;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int X_SLOTS = src_planes(0) * reg_p(HALO);          // 3744
-constexpr int X_DMA = (X_SLOTS + 255) / 256;                   // staging instructions per wave for x
+constexpr int HALO = 5;
 constexpr int NCHUNK_TOTAL = 4 + 6 + 8 + 10 + 2 * 12;          // weight chunks of a block
 // A wave multiplies the chunks of layers 0..3 and those of ONE 32-channel half of layer 4 (waves
-// split that layer 2 halves x 2 pixel-group pairs): 40 chunks stream through its registers.
+// split that layer 2 halves x 2 sets of pixel groups): 40 chunks stream through its registers.
 constexpr int NCHUNK_WAVE = 4 + 6 + 8 + 10 + 12;
 constexpr unsigned WCHUNK_BYTES = 9 * 512 * 2;
 constexpr unsigned OOB = 0xFFFFFFF0u;
-
-// layer L = 0..4 (conv1..conv5): output halo, pixel groups of 32, groups per wave
-constexpr int out_halo(int L) { return L < 4 ? HALO - 1 - L : 0; }
-constexpr int out_p(int L) { return reg_p(out_halo(L)); }
-constexpr int out_groups(int L) { return (out_p(L) + 31) / 32; }            // 12 10 8 6 4
-// layer 4: each wave takes two of the four groups for one 32-channel half of the output
-constexpr int rw_max(int L) { return L == 4 ? 2 : (out_groups(L) + 3) / 4; }   // 3 3 2 2 2
 // which waves take the odd groups alternates between the layers that have them
 constexpr int wave_rot(int L) { return L == 3 ? 2 : 0; }
 constexpr int bias_off(int L) { return 32 * L; }                            // floats; conv5: + 32 * pass
@@ -142,301 +119,337 @@ template <bool BWD> constexpr int in_plane0() { return BWD ? 16 : 0; }
 template <bool BWD> constexpr int slice_plane(int L) { return BWD ? 4 * (3 - L) : 8 + 4 * L; }
 constexpr int mask_plane(int L) { return 8 + 4 * (3 - L); }
 
-template <bool BWD, bool STORE>
-__global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
-  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, pl = lane & 31, hh = lane >> 5;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // layer 4: this wave's 32-channel half of the output and its pair of pixel groups
-  const int pass5 = wave_u & 1, pair5 = wave_u >> 1;
+// Geometry of a TW x TH-pixel output tile (TW * TH = 64 or 128 pixels) and the kernel body for it.
+// The 16 x 8 tile recomputes 1.5 x the arithmetic of the layer-by-layer form in its halos and needs
+// 132 KB of LDS; the 8 x 8 tile recomputes 1.85 x and needs 87 KB, and gives a small feature map
+// twice the workgroups.
+template <int TW, int TH>
+struct Tile {
+  static constexpr int reg_h(int halo) { return TH + 2 * halo; }
+  static constexpr int reg_w(int halo) { return TW + 2 * halo; }
+  static constexpr int reg_p(int halo) { return reg_h(halo) * reg_w(halo); }
+  // source s of a layer's input: 0 = block input (8 octet planes, halo 5); s = 1..4 = growth slice s
+  // (4 planes, halo 5 - s).  Regions are stored [plane][pixel of the region], 16-byte slots.
+  static constexpr int src_halo(int s) { return HALO - s; }
+  static constexpr int src_planes(int s) { return s == 0 ? 8 : 4; }
+  static constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * reg_p(src_halo(s - 1)); }
+  static constexpr int ACT_SLOTS = 8 * reg_p(5) + 4 * (reg_p(4) + reg_p(3) + reg_p(2) + reg_p(1));
+  static constexpr int BIAS_BASE = ACT_SLOTS;              // packed biases: 4 x 32 + 64 floats = 48 slots
+  static constexpr int LDS_SLOTS = BIAS_BASE + 64;
+  static constexpr int LDS_BYTES = LDS_SLOTS * 16;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static constexpr int X_SLOTS = 8 * reg_p(HALO);
+  static constexpr int X_DMA = (X_SLOTS + 255) / 256;           // staging instructions per wave for x
+  // layer L = 0..4 (conv1..conv5): output halo, pixel groups of 32, groups per wave
+  static constexpr int out_halo(int L) { return L < 4 ? HALO - 1 - L : 0; }
+  static constexpr int out_p(int L) { return reg_p(out_halo(L)); }
+  static constexpr int out_groups(int L) { return (out_p(L) + 31) / 32; }      // 16 x 8: 12 10 8 6 4;  8 x 8: 8 7 5 4 2
+  // layer 4: each wave takes half of the groups for one 32-channel half of the output
+  static constexpr int NG5 = TW * TH / 32;
+  static_assert(NG5 == 2 || NG5 == 4, "tile of 64 or 128 pixels");
+  static constexpr int rw_max(int L) { return L == 4 ? NG5 / 2 : (out_groups(L) + 3) / 4; }
+
+  template <bool BWD, bool STORE>
+  static __device__ __forceinline__ void run(const RdbParams& p, u32x4_* smem) {
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 31, hh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // layer 4: this wave's 32-channel half of the output and its pair of pixel groups
+    const int pass5 = wave_u & 1, pair5 = wave_u >> 1;
 #ifdef RDB_STAMPS
-  int stamp_k = 0;
-  auto stamp = [&]() {
-    const unsigned long long tnow = __builtin_readcyclecounter();
-    if (blockIdx.x == 8 && lane == 0 && p.stamps) p.stamps[wave_u * 16 + stamp_k] = tnow;
-    ++stamp_k;
-  };
-  stamp();
+    int stamp_k = 0;
+    auto stamp = [&]() {
+      const unsigned long long tnow = __builtin_readcyclecounter();
+      if (blockIdx.x == 8 && lane == 0 && p.stamps) p.stamps[wave_u * 16 + stamp_k] = tnow;
+      ++stamp_k;
+    };
+    stamp();
 #else
-  auto stamp = [] {};
+    auto stamp = [] {};
 #endif
 
-  // workgroup -> tile, one contiguous run of tiles per XCD (neighbouring tiles share most of their
-  // halo: they should meet in one XCD's L2)
-  unsigned t = blockIdx.x;
-  {
-    const unsigned chunk = (unsigned)p.total / 8u;
-    if (t < 8u * chunk) t = (t & 7u) * chunk + (t >> 3);
-  }
-  const int tx = (int)(t % (unsigned)p.tiles_x);
-  const unsigned tr = t / (unsigned)p.tiles_x;
-  const int ty = (int)(tr % (unsigned)p.tiles_y), b = (int)(tr / (unsigned)p.tiles_y);
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int H = p.H, W = p.W;
-  const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
-
-  bf16* const img = p.buf + (long)b * p.buf_is;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      img + (long)in_plane0<BWD>() * H * W * 8, 0, (int)(8u * plane_b), 0x00020000);
-  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(24u * plane_b), 0x00020000);
-  const __amdgpu_buffer_rsrc_t yrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.y_is, 0, (int)(8u * plane_b), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)(NCHUNK_TOTAL * WCHUNK_BYTES), 0x00020000);
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16*>(BWD ? p.act + (long)b * p.act_is : p.w), 0, (int)(BWD ? 24u * plane_b : 0u), 0x00020000);
-
-  // ---- the kernel's input (block input / g_out) over the tile + 5-pixel halo: X_DMA LDS-DMA
-  // instructions per wave; pixels outside the image (the zero padding) and the slots past the region
-  // get an out-of-range offset, for which the hardware deposits zeros (the few slots past the region
-  // belong to the first slice, which is written later)
-#pragma unroll
-  for (int j = 0; j < X_DMA; ++j) {
-    const unsigned slot = (unsigned)(j * 256 + tid);
-    const unsigned q = slot / (unsigned)reg_p(HALO), pix = slot - q * (unsigned)reg_p(HALO);
-    const unsigned r = pix / (unsigned)reg_w(HALO), c = pix - r * (unsigned)reg_w(HALO);
-    const int gy = oy0 - HALO + (int)r, gx = ox0 - HALO + (int)c;
-    const bool ok = (slot < (unsigned)X_SLOTS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-    const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
-  }
-  // packed biases (the accumulators' initial values) -> LDS; the data gradient has none
-  if (!BWD && tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
-
-  // ---- weights: every wave multiplies all 32 output channels of a chunk, so every lane reads its own
-  // 16-byte fragment of each of the nine taps straight into registers (1 KB per wave instruction,
-  // served by the L1 after the first wave), WDEPTH chunks ahead of the multiply.  Nothing but the
-  // activations lives in LDS, so no barrier is needed inside a layer.  Position n of a wave's chunk
-  // stream is chunk n of the packed block for layers 0..3 and chunk n + 12 * (its half) for layer 4.
-  const unsigned wlane = (unsigned)(hh * 32 + pl) * 16u;
-  constexpr int WDEPTH = 3;                  // chunks in flight ahead of the multiply (L2 latency under load: about 1 us)
-  u32x4_ wbuf[WDEPTH + 1][9];
-  auto chunk_bytes = [&](int n) -> unsigned {          // n: compile-time after unrolling
-    return n < layer_chunk0(4) ? (unsigned)n * WCHUNK_BYTES : (unsigned)(n + 12 * pass5) * WCHUNK_BYTES;
-  };
-  auto load_w = [&](int n, u32x4_ (&dst)[9]) {
-#ifdef RDB_ABLATE_NO_WLOAD
-    if (n >= 1) return;                       // timing-only build: weight fragments are never refreshed
-#endif
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-      dst[tp] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)tp * 1024u, chunk_bytes(n), 0);
-  };
-#pragma unroll
-  for (int n0 = 0; n0 < WDEPTH; ++n0) load_w(n0, wbuf[n0]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the input tile has landed (this wave's share) ...
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                             // ... and every other wave's, and the biases
-  stamp();
-#ifdef RDB_ABLATE_EXIT_AFTER_STAGE
-  if (p.total > 0) return;                     // timing-only build: launch + input staging alone
-#endif
-
-  const bf16x8* const lds = reinterpret_cast<const bf16x8*>(smem);
-  bf16x8* const ldsw = reinterpret_cast<bf16x8*>(smem);
-  const float* const lbias = reinterpret_cast<const float*>(smem + BIAS_BASE);
-
-  static_for<5>([&](auto Lc) {
-    constexpr int L = decltype(Lc)::value;
-    constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
-#ifdef RDB_ABLATE_LAYERS
-    if (L >= RDB_ABLATE_LAYERS) return;         // timing-only build: the first layers alone
-#endif
-    // this wave's pixel groups.  Layers 0..3: g = rg * 4 + ((wave + rot) & 3), only the last rg can be
-    // missing (the wave then multiplies a dummy group whose results are dropped: the waves that have
-    // the group set the layer's length anyway); layer 4: the pair of groups 2 * pair5 + rg.
-    const int wsel = (wave_u + wave_rot(L)) & 3;
-    const bool last_valid = L == 4 || (RW - 1) * 4 + wsel < NG;          // wave-uniform
-    int py[RW], px[RW], pp[RW];
-#pragma unroll
-    for (int rg = 0; rg < RW; ++rg) {
-      pp[rg] = (L == 4 ? 2 * pair5 + rg : rg * 4 + wsel) * 32 + pl;
-      const int pc = pp[rg] < OP ? pp[rg] : OP - 1;
-      py[rg] = pc / OWd;
-      px[rg] = pc - py[rg] * OWd;
+    // workgroup -> tile, one contiguous run of tiles per XCD (neighbouring tiles share most of their
+    // halo: they should meet in one XCD's L2)
+    unsigned t = blockIdx.x;
+    {
+      const unsigned chunk = (unsigned)p.total / 8u;
+      if (t < 8u * chunk) t = (t & 7u) * chunk + (t >> 3);
     }
-    // BWD: LeakyReLU'(x_j) of this wave's pixels, read from the activation buffer in front of the K
-    // loop (two octets per lane and group); pixels outside the image read zeros and are zeroed anyway
-    [[maybe_unused]] u32x4_ mk[RW][2];
-    if constexpr (BWD && L < 4) {
+    const int tx = (int)(t % (unsigned)p.tiles_x);
+    const unsigned tr = t / (unsigned)p.tiles_x;
+    const int ty = (int)(tr % (unsigned)p.tiles_y), b = (int)(tr / (unsigned)p.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int H = p.H, W = p.W;
+    const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
+
+    bf16* const img = p.buf + (long)b * p.buf_is;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        img + (long)in_plane0<BWD>() * H * W * 8, 0, (int)(8u * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(img, 0, (int)(24u * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.y_is, 0, (int)(8u * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)(NCHUNK_TOTAL * WCHUNK_BYTES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(BWD ? p.act + (long)b * p.act_is : p.w), 0, (int)(BWD ? 24u * plane_b : 0u), 0x00020000);
+
+    // ---- the kernel's input (block input / g_out) over the tile + 5-pixel halo: X_DMA LDS-DMA
+    // instructions per wave; pixels outside the image (the zero padding) and the slots past the region
+    // get an out-of-range offset, for which the hardware deposits zeros (the few slots past the region
+    // belong to the first slice, which is written later)
+#pragma unroll
+    for (int j = 0; j < X_DMA; ++j) {
+      const unsigned slot = (unsigned)(j * 256 + tid);
+      const unsigned q = slot / (unsigned)reg_p(HALO), pix = slot - q * (unsigned)reg_p(HALO);
+      const unsigned r = pix / (unsigned)reg_w(HALO), c = pix - r * (unsigned)reg_w(HALO);
+      const int gy = oy0 - HALO + (int)r, gx = ox0 - HALO + (int)c;
+      const bool ok = (slot < (unsigned)X_SLOTS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+      const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
+    }
+    // packed biases (the accumulators' initial values) -> LDS; the data gradient has none
+    if (!BWD && tid < 48) *reinterpret_cast<f32x4*>(smem + BIAS_BASE + tid) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+
+    // ---- weights: every wave multiplies all 32 output channels of a chunk, so every lane reads its own
+    // 16-byte fragment of each of the nine taps straight into registers (1 KB per wave instruction,
+    // served by the L1 after the first wave), WDEPTH chunks ahead of the multiply.  Nothing but the
+    // activations lives in LDS, so no barrier is needed inside a layer.  Position n of a wave's chunk
+    // stream is chunk n of the packed block for layers 0..3 and chunk n + 12 * (its half) for layer 4.
+    const unsigned wlane = (unsigned)(hh * 32 + pl) * 16u;
+    constexpr int WDEPTH = 3;                  // chunks in flight ahead of the multiply (L2 latency under load: about 1 us)
+    u32x4_ wbuf[WDEPTH + 1][9];
+    auto chunk_bytes = [&](int n) -> unsigned {          // n: compile-time after unrolling
+      return n < layer_chunk0(4) ? (unsigned)n * WCHUNK_BYTES : (unsigned)(n + 12 * pass5) * WCHUNK_BYTES;
+    };
+    auto load_w = [&](int n, u32x4_ (&dst)[9]) {
+#ifdef RDB_ABLATE_NO_WLOAD
+      if (n >= 1) return;                       // timing-only build: weight fragments are never refreshed
+#endif
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+        dst[tp] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)tp * 1024u, chunk_bytes(n), 0);
+    };
+#pragma unroll
+    for (int n0 = 0; n0 < WDEPTH; ++n0) load_w(n0, wbuf[n0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the input tile has landed (this wave's share) ...
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // ... and every other wave's, and the biases
+    stamp();
+#ifdef RDB_ABLATE_EXIT_AFTER_STAGE
+    if (p.total > 0) return;                     // timing-only build: launch + input staging alone
+#endif
+
+    const bf16x8* const lds = reinterpret_cast<const bf16x8*>(smem);
+    bf16x8* const ldsw = reinterpret_cast<bf16x8*>(smem);
+    const float* const lbias = reinterpret_cast<const float*>(smem + BIAS_BASE);
+
+    static_for<5>([&](auto Lc) {
+      constexpr int L = decltype(Lc)::value;
+      constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
+#ifdef RDB_ABLATE_LAYERS
+      if (L >= RDB_ABLATE_LAYERS) return;         // timing-only build: the first layers alone
+#endif
+      // this wave's pixel groups.  Layers 0..3: g = rg * 4 + ((wave + rot) & 3), only the last rg can be
+      // missing (the wave then multiplies a dummy group whose results are dropped: the waves that have
+      // the group set the layer's length anyway); layer 4: the pair of groups 2 * pair5 + rg.
+      const int wsel = (wave_u + wave_rot(L)) & 3;
+      const bool last_valid = L == 4 || (RW - 1) * 4 + wsel < NG;          // wave-uniform
+      int py[RW], px[RW], pp[RW];
 #pragma unroll
       for (int rg = 0; rg < RW; ++rg) {
-        const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
-        const bool ok = (rg < RW - 1 || last_valid) && pp[rg] < OP && ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mk[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
-              arsrc, ok ? (unsigned)(mask_plane(L) + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
+        pp[rg] = (L == 4 ? pair5 * (NG5 / 2) + rg : rg * 4 + wsel) * 32 + pl;
+        const int pc = pp[rg] < OP ? pp[rg] : OP - 1;
+        py[rg] = pc / OWd;
+        px[rg] = pc - py[rg] * OWd;
       }
-    }
+      // BWD: LeakyReLU'(x_j) of this wave's pixels, read from the activation buffer in front of the K
+      // loop (two octets per lane and group); pixels outside the image read zeros and are zeroed anyway
+      [[maybe_unused]] u32x4_ mk[RW][2];
+      if constexpr (BWD && L < 4) {
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) {
+          const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
+          const bool ok = (rg < RW - 1 || last_valid) && pp[rg] < OP && ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            mk[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                arsrc, ok ? (unsigned)(mask_plane(L) + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
+        }
+      }
 
-    // last layer: the second residual of this wave's pixels, likewise read in front of the K loop
-    [[maybe_unused]] u32x4_ r2w[RW][2];
-    if constexpr (L == 4) {
-      if (p.res2 != nullptr) {
-        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16*>(p.res2 + (long)b * p.r2_is), 0, (int)(8u * plane_b), 0x00020000);
+      // last layer: the second residual of this wave's pixels, likewise read in front of the K loop
+      [[maybe_unused]] u32x4_ r2w[RW][2];
+      if constexpr (L == 4) {
+        if (p.res2 != nullptr) {
+          const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<bf16*>(p.res2 + (long)b * p.r2_is), 0, (int)(8u * plane_b), 0x00020000);
+#pragma unroll
+          for (int rg = 0; rg < RW; ++rg) {
+            const int gy = oy0 + py[rg], gx = ox0 + px[rg];
+            const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              r2w[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                  rrsrc, in_img ? (unsigned)(pass5 * 4 + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
+          }
+        }
+      }
+
+      f32x16 acc[RW];
+      if constexpr (BWD) {
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rg][i] = 0.f;
+      } else {
+        const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + (L == 4 ? 32 * pass5 : 0) + hh * 16);
+        const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
+          }
+      }
+      // K loop: 16 channels a step, sources in the channel order of the buffer.  The activation
+      // fragments of a tap row are read while the row before it is multiplied, across chunk boundaries
+      // too: with one wave per SIMD nothing else hides the LDS latency.
+      constexpr int NC = layer_nchunks(L);
+      int ps[L + 1][RW];                              // per source: this lane's pixel at tap (0, 0)
+      static_for<L + 1>([&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr int SW = reg_w(src_halo(S)), O = L - S;   // O: offset of this layer's region inside the source's, minus the tap pad
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) ps[S][rg] = (py[rg] + O) * SW + px[rg] + O;
+      });
+      bf16x8 xf[2][3][RW];
+      auto read_row = [&](auto Ic, int dy, bf16x8 (&dst)[3][RW]) {
+        constexpr int i = decltype(Ic)::value;
+        constexpr int S = chunk_src<BWD>(L, i), cc = chunk_cc<BWD>(L, i);
+        constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
+        const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int rg = 0; rg < RW; ++rg) dst[dx][rg] = sx[ps[S][rg] + dx];
+      };
+      read_row(std::integral_constant<int, 0>{}, 0, xf[0]);
+      static_for<NC>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        constexpr int n = layer_chunk0(L) + i;
+        constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
+        constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
+        const unsigned noff = chunk_bytes(n + WDEPTH);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int cur = (3 * i + dy) & 1;
+          if (dy < 2) read_row(Ic, dy + 1, xf[cur ^ 1]);
+          else if constexpr (i + 1 < NC) read_row(std::integral_constant<int, i + 1>{}, 0, xf[cur ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+
+      stamp();
+      if constexpr (L < 4) {
+        // forward: bias is in the accumulators, LeakyReLU; backward: times LeakyReLU'(x_j).  Zero outside
+        // the image (the next layer's padding); into LDS for the layers behind, and the tile's own
+        // pixels to the buffer (the backward pass / the weight gradients read them)
+#pragma unroll
+        for (int rg = 0; rg < RW; ++rg) {
+          const bool has = rg < RW - 1 || last_valid;                 // wave-uniform
+          const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
+          const bool lane_ok = has && pp[rg] < OP;
+          const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+          const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            // (this tail is straight VALU work in front of a barrier: instruction count is its price.
+            //  The maximum is taken by v_max_f32 itself: fmaxf() first quiets signalling NaNs with a
+            //  second v_max per value; the mask's sign is tested on the bf16 bit patterns; pixels
+            //  outside the image are zeroed on the packed words)
+            bf16x8 o;
+            if constexpr (BWD) {
+              const u32x4_ mw = mk[rg][j];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float v = acc[rg][j * 8 + e];
+                const bool pos = (e & 1) ? (int)mw[e >> 1] > 0xFFFF : (short)(mw[e >> 1] & 0xFFFFu) > 0;
+                o[e] = (bf16)(pos ? v : v * p.slope);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float v = acc[rg][j * 8 + e], t = v * p.slope;
+                float r;
+                asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+                o[e] = (bf16)r;
+              }
+            }
+            {
+              u32x4_ ow = __builtin_bit_cast(u32x4_, o);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) ow[k] = in_img ? ow[k] : 0u;
+              o = __builtin_bit_cast(bf16x8, ow);
+            }
+            const int oct = 2 * j + hh;
+            if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
+            if constexpr (STORE) {
+              const unsigned off = own ? (unsigned)(slice_plane<BWD>(L) + oct) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), grsrc, off, 0, 0);
+            }
+          }
+        }
+        // the next layer reads what every wave has just written
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stamp();
+      } else {
+        // last layer: alpha * y + beta1 * (the kernel's input) + beta2 * res2 for this wave's 32 channels
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg) {
           const int gy = oy0 + py[rg], gx = ox0 + px[rg];
           const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            r2w[rg][j] = __builtin_amdgcn_raw_buffer_load_b128(
-                rrsrc, in_img ? (unsigned)(pass5 * 4 + 2 * j + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB, 0, 0);
-        }
-      }
-    }
-
-    f32x16 acc[RW];
-    if constexpr (BWD) {
-#pragma unroll
-      for (int rg = 0; rg < RW; ++rg)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[rg][i] = 0.f;
-    } else {
-      const f32x4* bv = reinterpret_cast<const f32x4*>(lbias + bias_off(L) + (L == 4 ? 32 * pass5 : 0) + hh * 16);
-      const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
-#pragma unroll
-      for (int rg = 0; rg < RW; ++rg)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
-        }
-    }
-    // K loop: 16 channels a step, sources in the channel order of the buffer.  The activation
-    // fragments of a tap row are read while the row before it is multiplied, across chunk boundaries
-    // too: with one wave per SIMD nothing else hides the LDS latency.
-    constexpr int NC = layer_nchunks(L);
-    int ps[L + 1][RW];                              // per source: this lane's pixel at tap (0, 0)
-    static_for<L + 1>([&](auto Sc) {
-      constexpr int S = decltype(Sc)::value;
-      constexpr int SW = reg_w(src_halo(S)), O = L - S;   // O: offset of this layer's region inside the source's, minus the tap pad
-#pragma unroll
-      for (int rg = 0; rg < RW; ++rg) ps[S][rg] = (py[rg] + O) * SW + px[rg] + O;
-    });
-    bf16x8 xf[2][3][RW];
-    auto read_row = [&](auto Ic, int dy, bf16x8 (&dst)[3][RW]) {
-      constexpr int i = decltype(Ic)::value;
-      constexpr int S = chunk_src<BWD>(L, i), cc = chunk_cc<BWD>(L, i);
-      constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
-      const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int rg = 0; rg < RW; ++rg) dst[dx][rg] = sx[ps[S][rg] + dx];
-    };
-    read_row(std::integral_constant<int, 0>{}, 0, xf[0]);
-    static_for<NC>([&](auto Ic) {
-      constexpr int i = decltype(Ic)::value;
-      constexpr int n = layer_chunk0(L) + i;
-      constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
-      constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
-      const unsigned noff = chunk_bytes(n + WDEPTH);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int cur = (3 * i + dy) & 1;
-        if (dy < 2) read_row(Ic, dy + 1, xf[cur ^ 1]);
-        else if constexpr (i + 1 < NC) read_row(std::integral_constant<int, i + 1>{}, 0, xf[cur ^ 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    });
-
-    stamp();
-    if constexpr (L < 4) {
-      // forward: bias is in the accumulators, LeakyReLU; backward: times LeakyReLU'(x_j).  Zero outside
-      // the image (the next layer's padding); into LDS for the layers behind, and the tile's own
-      // pixels to the buffer (the backward pass / the weight gradients read them)
-#pragma unroll
-      for (int rg = 0; rg < RW; ++rg) {
-        const bool has = rg < RW - 1 || last_valid;                 // wave-uniform
-        const int gy = oy0 - OH_ + py[rg], gx = ox0 - OH_ + px[rg];
-        const bool lane_ok = has && pp[rg] < OP;
-        const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-        const bool own = lane_ok && in_img && py[rg] >= OH_ && py[rg] < OH_ + TH && px[rg] >= OH_ && px[rg] < OH_ + TW;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // (this tail is straight VALU work in front of a barrier: instruction count is its price.
-          //  The maximum is taken by v_max_f32 itself: fmaxf() first quiets signalling NaNs with a
-          //  second v_max per value; the mask's sign is tested on the bf16 bit patterns; pixels
-          //  outside the image are zeroed on the packed words)
-          bf16x8 o;
-          if constexpr (BWD) {
-            const u32x4_ mw = mk[rg][j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float v = acc[rg][j * 8 + e];
-              const bool pos = (e & 1) ? (int)mw[e >> 1] > 0xFFFF : (short)(mw[e >> 1] & 0xFFFFu) > 0;
-              o[e] = (bf16)(pos ? v : v * p.slope);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float v = acc[rg][j * 8 + e], t = v * p.slope;
-              float r;
-              asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
-              o[e] = (bf16)r;
-            }
-          }
-          {
-            u32x4_ ow = __builtin_bit_cast(u32x4_, o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ow[k] = in_img ? ow[k] : 0u;
-            o = __builtin_bit_cast(bf16x8, ow);
-          }
-          const int oct = 2 * j + hh;
-          if (lane_ok) ldsw[src_base(L + 1) + oct * OP + pp[rg]] = o;
-          if constexpr (STORE) {
-            const unsigned off = own ? (unsigned)(slice_plane<BWD>(L) + oct) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), grsrc, off, 0, 0);
-          }
-        }
-      }
-      // the next layer reads what every wave has just written
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stamp();
-    } else {
-      // last layer: alpha * y + beta1 * (the kernel's input) + beta2 * res2 for this wave's 32 channels
-#pragma unroll
-      for (int rg = 0; rg < RW; ++rg) {
-        const int gy = oy0 + py[rg], gx = ox0 + px[rg];
-        const bool in_img = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-        const int xs = (py[rg] + HALO) * reg_w(HALO) + px[rg] + HALO;
-        if (p.alpha != 1.f) acc[rg] *= p.alpha;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int oct = pass5 * 4 + 2 * j + hh;
-          const bf16x8 xr = lds[src_base(0) + oct * reg_p(HALO) + xs];
-          const float b1 = p.beta1;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b1 * (float)xr[e];
-        }
-        if (p.res2 != nullptr) {
-          const float b2 = p.beta2;
+          const int xs = (py[rg] + HALO) * reg_w(HALO) + px[rg] + HALO;
+          if (p.alpha != 1.f) acc[rg] *= p.alpha;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const bf16x8 r2 = __builtin_bit_cast(bf16x8, r2w[rg][j]);
+            const int oct = pass5 * 4 + 2 * j + hh;
+            const bf16x8 xr = lds[src_base(0) + oct * reg_p(HALO) + xs];
+            const float b1 = p.beta1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b2 * (float)r2[e];
+            for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b1 * (float)xr[e];
+          }
+          if (p.res2 != nullptr) {
+            const float b2 = p.beta2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const bf16x8 r2 = __builtin_bit_cast(bf16x8, r2w[rg][j]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b2 * (float)r2[e];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int oct = pass5 * 4 + 2 * j + hh;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[rg][j * 8 + e];
+            const unsigned off = in_img ? (unsigned)oct * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
           }
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int oct = pass5 * 4 + 2 * j + hh;
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[rg][j * 8 + e];
-          const unsigned off = in_img ? (unsigned)oct * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), yrsrc, off, 0, 0);
-        }
+        stamp();
       }
-      stamp();
-    }
-  });
+    });
+  }
+};
+
+template <bool BWD, bool STORE, int TW, int TH>
+__global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
+  Tile<TW, TH>::template run<BWD, STORE>(p, smem);
 }
 
 }  // namespace
@@ -445,6 +458,21 @@ __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
 static unsigned long long* g_rdb_stamps = nullptr;
 extern "C" void srx_rdb_debug_stamps(void* buf) { g_rdb_stamps = static_cast<unsigned long long*>(buf); }
 #endif
+
+template <bool BWD, bool STORE, int TW, int TH>
+static int rdb_launch_tile(RdbParams p, const srx_rdb_desc* d, hipStream_t s, const char* who) {
+  constexpr int LDS_BYTES = Tile<TW, TH>::LDS_BYTES;
+  p.tiles_x = (d->W + TW - 1) / TW;
+  p.tiles_y = (d->H + TH - 1) / TH;
+  const long total = (long)p.tiles_x * p.tiles_y * d->B;
+  SRX_CHECK_ARG(total < (1L << 31), "%s: grid out of range", who);
+  p.total = (int)total;
+  static srx_per_device_once attr;         // per instantiation, per device
+  auto kern = rdb_kernel<BWD, STORE, TW, TH>;
+  if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(kern), LDS_BYTES)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+  return srx_check_launch(BWD ? "rdb_kernel (backward)" : "rdb_kernel (forward)");
+}
 
 static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char* who) {
   SRX_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
@@ -467,29 +495,18 @@ static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char*
   p.act = static_cast<const bf16*>(d->act); p.act_is = d->act_img_stride;
   p.slope = d->act_slope; p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2;
   p.H = d->H; p.W = d->W;
-  p.tiles_x = (d->W + TW - 1) / TW;
-  p.tiles_y = (d->H + TH - 1) / TH;
-  const long total = (long)p.tiles_x * p.tiles_y * d->B;
-  SRX_CHECK_ARG(total < (1L << 31), "%s: grid out of range", who);
-  p.total = (int)total;
+  SRX_CHECK_ARG(d->tile == 0 || d->tile == 1, "%s: tile must be 0 (16 x 8) or 1 (8 x 8), got %d", who, d->tile);
 #ifdef RDB_STAMPS
   p.stamps = g_rdb_stamps;
 #endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (bwd) {
-    static srx_per_device_once attr;
-    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<true, true>), LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((rdb_kernel<true, true>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
-  } else if (d->store_growth) {
-    static srx_per_device_once attr;
-    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<false, true>), LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((rdb_kernel<false, true>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
-  } else {
-    static srx_per_device_once attr;
-    if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(rdb_kernel<false, false>), LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((rdb_kernel<false, false>), dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
+  const int mode = bwd ? 2 : (d->store_growth ? 1 : 0);
+  if (d->tile == 0) {
+    if (mode == 2) return rdb_launch_tile<true, true, 16, 8>(p, d, s, who);
+    return mode == 1 ? rdb_launch_tile<false, true, 16, 8>(p, d, s, who) : rdb_launch_tile<false, false, 16, 8>(p, d, s, who);
   }
-  return srx_check_launch(bwd ? "rdb_kernel (backward)" : "rdb_kernel (forward)");
+  if (mode == 2) return rdb_launch_tile<true, true, 8, 8>(p, d, s, who);
+  return mode == 1 ? rdb_launch_tile<false, true, 8, 8>(p, d, s, who) : rdb_launch_tile<false, false, 8, 8>(p, d, s, who);
 }
 
 extern "C" int srx_rdb_forward(const srx_rdb_desc* d, void* stream) { return rdb_launch(d, stream, false, "srx_rdb_forward"); }

@@ -678,6 +678,24 @@ class _GenBase(Plan):
             return False
         return bool(self.fused_rdb_bwd) or B * _ceil(h, 8) * _ceil(w, 16) <= self.fused_rdb_bwd_max_tiles
 
+    # Tile of the fused kernels: 16 x 8 pixels per workgroup; 8 x 8 for inference plans whose feature
+    # map that still fits the chip in one round (twice the workgroups for a fifth more arithmetic:
+    # 16 x 32 x 32 stand-alone 23.5 -> 20.7 us per block).  Training plans keep 16 x 8: the work of
+    # the side stream (weight gradients in backward; the discriminator / VGG passes on the real batch
+    # beside the generator's forward in the adversarial step) runs on the CUs the larger tiles leave
+    # free (config 3, A/B on one box: 7.84 ms per step with 16 x 8 in both passes, 8.00 with 8 x 8 in
+    # forward, 8.12 in both).  SRX_RDB_TILE_FWD / SRX_RDB_TILE_BWD = 0 / 1 force 16 x 8 / 8 x 8.
+    rdb_tile_fwd = {"0": 0, "1": 1}.get(os.environ.get("SRX_RDB_TILE_FWD", "auto"))
+    rdb_tile_bwd = {"0": 0, "1": 1}.get(os.environ.get("SRX_RDB_TILE_BWD", "auto"))
+
+    def rdb_tile(self, B: int, h: int, w: int, backward: bool) -> int:
+        forced = self.rdb_tile_bwd if backward else self.rdb_tile_fwd
+        if forced is not None:
+            return forced
+        if backward or self.need_grad:
+            return 0
+        return 1 if B * _ceil(h, 8) * _ceil(w, 8) <= 256 else 0
+
     def rdb_fwd(self, ops: list, cur: Buf, dst: View, w_ptr: int, bias_ptr: int, B: int, h: int, w: int,
                 nf: int, gc: int, store_growth: bool, alpha: float, beta1: float,
                 res2: Optional[View] = None, beta2: float = 0.0, backward_of: Optional[Buf] = None):
@@ -688,6 +706,7 @@ class _GenBase(Plan):
         d = op.u.rdb
         d.dtype, d.B, d.H, d.W, d.nf, d.gc = self.dt, B, h, w, nf, gc
         d.store_growth = 1 if store_growth else 0
+        d.tile = self.rdb_tile(B, h, w, backward_of is not None)
         d.buf, d.buf_img_stride = cur.ptr(0), cur.img_stride
         d.y, d.y_img_stride = dst[0].ptr(dst[1]), dst[0].img_stride
         d.w, d.bias = w_ptr, bias_ptr or None

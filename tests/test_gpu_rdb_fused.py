@@ -11,19 +11,21 @@ from helpers import O, fill_module_, pkg
 pytestmark = pytest.mark.gpu
 
 
-def _plans(shape, need_grad, num_blocks=2, fused_bwd=False):
-    """(layer-by-layer plan, plan with the fused forward [and the fused data gradient])"""
+def _plans(shape, need_grad, num_blocks=2, fused_bwd=False, tile=0):
+    """(layer-by-layer plan, plan with the fused forward [and the fused data gradient]) on 16 x 8
+    (tile 0) or 8 x 8 (tile 1) pixel tiles"""
     E, G = pkg("engine"), pkg("esrgan.generator")
     g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=51).cuda()
     params = {n: p.data for n, p in g.named_parameters()}
     B, h, w = shape
-    out, keep = [], (E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd)
+    out, keep = [], (E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd, E._GenBase.rdb_tile_fwd, E._GenBase.rdb_tile_bwd)
     for fused in (False, True):
         E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd = fused, fused and fused_bwd
+        E._GenBase.rdb_tile_fwd = E._GenBase.rdb_tile_bwd = tile
         try:
             out.append(E.GeneratorPlan(params, B, h, w, torch.bfloat16, num_blocks=num_blocks, need_grad=need_grad))
         finally:
-            E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd = keep
+            (E._GenBase.fused_rdb, E._GenBase.fused_rdb_bwd, E._GenBase.rdb_tile_fwd, E._GenBase.rdb_tile_bwd) = keep
     names = [[m[0] for m in p.fwd_meta] for p in out]
     assert "rdb_fwd_kernel" not in names[0] and names[1].count("rdb_fwd_kernel") == 3 * num_blocks
     if need_grad:
@@ -33,10 +35,11 @@ def _plans(shape, need_grad, num_blocks=2, fused_bwd=False):
     return out
 
 
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("need_grad", [True, False])
 @pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
-def test_fused_block_forward_equals_layer_by_layer(shape, need_grad):
-    ref, fus = _plans(shape, need_grad)
+def test_fused_block_forward_equals_layer_by_layer(shape, need_grad, tile):
+    ref, fus = _plans(shape, need_grad, tile=tile)
     x = O.hash_input("fr.x", (shape[0], 3, shape[1], shape[2])).cuda()
     y0 = ref.forward(x)
     y1 = fus.forward(x)
@@ -69,12 +72,13 @@ def test_fused_block_backward_uses_the_stored_growth_slices():
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
-def test_fused_block_data_gradient_equals_layer_by_layer(shape):
+def test_fused_block_data_gradient_equals_layer_by_layer(shape, tile):
     """srx_rdb_backward against the five data-gradient launches: every gradient buffer
     (gy1..gy4 | g_out of every block) and the gradient reaching conv_first's output bit for bit;
     the parameter gradients up to the summation order of the weight-gradient atomics."""
-    ref, fus = _plans(shape, True, fused_bwd=True)
+    ref, fus = _plans(shape, True, fused_bwd=True, tile=tile)
     B, h, w = shape
     x = O.hash_input("fb.x", (B, 3, h, w)).cuda()
     gy = O.hash_input("fb.gy", (B, 3, 4 * h, 4 * w)).cuda() / (B * 3 * 16 * h * w)
@@ -103,6 +107,8 @@ def test_fused_block_rejects_what_it_does_not_cover():
     d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32)
     assert lib.srx_rdb_backward(d, None) == 1 and b"null buf" in lib.srx_last_error()
     assert lib.srx_rdb_backward(None, None) == 1
+    d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32, tile=2, buf=256, y=256, w=256, bias=256)
+    assert lib.srx_rdb_forward(d, None) == 1 and b"tile must be" in lib.srx_last_error()
 
 
 def test_fused_block_is_chosen_by_size():
