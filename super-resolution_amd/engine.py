@@ -655,12 +655,13 @@ class _GenBase(Plan):
 
     # One launch per dense block forward (csrc/rdb.hip) where the shape allows it (bf16, 64 block
     # channels, 32 growth channels) and where it is the faster form: while its 16 x 8-pixel tiles
-    # fit the chip in one round (at most one workgroup per CU).  Measured per block, 16 images:
-    # 32 x 32 (128 tiles) 27.9 us fused against 34.8 us as five launches; 64 x 64 (512 tiles, two
-    # rounds) 63.7 against 53.8; 64 images of 128 x 128: 854 against 518.
+    # fit the chip in at most two rounds (one workgroup per CU).  Per training step, A/B on one box,
+    # fused against five launches per block: 16 x 32 x 32 (128 tiles, config 3) 9.27 against 9.9 ms;
+    # 16 x 64 x 64 (512 tiles, config 2) 10.13 against 10.47; 32 x 64 x 64 (1 024 tiles) 18.1 against
+    # 17.1; 16 x 128 x 128 34.7 against 30.6.
     # SRX_FUSED_RDB=0 / 1 forces the five-launch / the fused form (A/B runs, tests).
     fused_rdb = {"0": False, "1": True}.get(os.environ.get("SRX_FUSED_RDB", "auto"))
-    fused_rdb_max_tiles = 256
+    fused_rdb_max_tiles = 512
 
     def use_fused_rdb(self, B: int, h: int, w: int, nf: int, gc: int) -> bool:
         if self.dt != L.BF16 or (nf, gc) != (64, 32) or self.fused_rdb is False:
@@ -669,7 +670,8 @@ class _GenBase(Plan):
 
     # The same for the data gradient of a dense block (srx_rdb_backward).  Beside it the weight
     # gradients of the side stream find no room on a CU it occupies (132 KB of LDS): only where its
-    # tiles leave CUs free.  SRX_FUSED_RDB_BWD=0 / 1 forces the choice.
+    # tiles leave CUs free (config 3, 128 tiles: 8.99 -> 8.41 ms per step; config 2, 512 tiles: 10.1 ->
+    # 11.9).  SRX_FUSED_RDB_BWD=0 / 1 forces the choice.
     fused_rdb_bwd = {"0": False, "1": True}.get(os.environ.get("SRX_FUSED_RDB_BWD", "auto"))
     fused_rdb_bwd_max_tiles = 256
 

@@ -112,13 +112,20 @@ def test_fused_block_rejects_what_it_does_not_cover():
 
 
 def test_fused_block_is_chosen_by_size():
-    """Left to itself a plan takes the fused form while its tiles fit the chip in one round."""
+    """Left to itself a plan takes the fused forward while its tiles fit the chip in two rounds, the
+    fused data gradient while they fit in one."""
     E, G = pkg("engine"), pkg("esrgan.generator")
     g = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=52).cuda()
     params = {n: p.data for n, p in g.named_parameters()}
     assert E._GenBase.fused_rdb is None
     small = E.GeneratorPlan(params, 16, 32, 32, torch.bfloat16, num_blocks=1, need_grad=False)
-    large = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, num_blocks=1, need_grad=False)
+    large = E.GeneratorPlan(params, 32, 64, 64, torch.bfloat16, num_blocks=1, need_grad=False)
     f32 = E.GeneratorPlan(params, 2, 16, 16, torch.float32, num_blocks=1, need_grad=False)
     assert [m[0] for m in small.fwd_meta].count("rdb_fwd_kernel") == 3
     assert all(m[0] != "rdb_fwd_kernel" for m in large.fwd_meta + f32.fwd_meta)
+    assert E._GenBase.fused_rdb_bwd is None
+    t128 = E.GeneratorPlan(params, 16, 32, 32, torch.bfloat16, num_blocks=1, need_grad=True)
+    t512 = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, num_blocks=1, need_grad=True)
+    assert [m[0] for m in t128.bwd_meta].count("rdb_bwd_kernel") == 3
+    assert [m[0] for m in t512.fwd_meta].count("rdb_fwd_kernel") == 3
+    assert all(m[0] != "rdb_bwd_kernel" for m in t512.bwd_meta)
