@@ -79,12 +79,15 @@ __device__ __forceinline__ void mma16(const bf16x8& a, const bf16x8& b, f32x16& 
 
 // One tap row (three taps) of one 16-channel chunk for R pixel groups: A = the chunk's weight
 // fragments of that row (in registers), B = the activation fragments at the three tap shifts, read
-// from the LDS-resident regions one tap row ahead (the caller reads row r + 1, or the first row of
-// the next chunk, in front of this call).  Same order of accumulation as conv_kernel: tap rows,
-// taps, groups.
-template <int R, bool PREFETCH>
+// from the LDS-resident regions one tap row ahead: behind every MFMA of this row goes one fragment
+// read of the next row (next_read(dx, rg)), so that the reads never hold the instruction stream
+// for longer than the gap between two MFMAs (nine reads issued as a block in front of the row cost
+// the matrix pipe about 40 idle cycles per row).  Same order of accumulation as conv_kernel: tap
+// rows, taps, groups.
+template <int R, bool PREFETCH, typename NextRead>
 __device__ __forceinline__ void row_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)[9], __amdgpu_buffer_rsrc_t wrsrc,
-                                        unsigned wlane, unsigned wnext_off, int dy, const bf16x8 (&xf)[3][R], f32x16* acc) {
+                                        unsigned wlane, unsigned wnext_off, int dy, const bf16x8 (&xf)[3][R], f32x16* acc,
+                                        NextRead&& next_read) {
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
@@ -93,6 +96,8 @@ __device__ __forceinline__ void row_mma(const u32x4_ (&wf)[9], u32x4_ (&wnext)[9
       if (dy + dx > 0) { asm volatile("" :: "v"(xf[dx][rg]), "v"(wf[dy * 3 + dx])); continue; }   // timing-only build
 #endif
       mma16(__builtin_bit_cast(bf16x8, wf[dy * 3 + dx]), xf[dx][rg], acc[rg]);
+      next_read(dx, rg);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // the weight fragment of the same tap of a later chunk, one load per tap: nine loads issued
     // back to back by four waves at once queue up in the address unit (16 cycles each) and hold
@@ -323,17 +328,21 @@ struct Tile {
         for (int rg = 0; rg < RW; ++rg) ps[S][rg] = (py[rg] + O) * SW + px[rg] + O;
       });
       bf16x8 xf[2][3][RW];
-      auto read_row = [&](auto Ic, int dy, bf16x8 (&dst)[3][RW]) {
+      // base of chunk i's fragments of tap row dy for this lane's k half (ps[S][rg] + dx is added per read)
+      auto row_base = [&](auto Ic, int dy) -> const bf16x8* {
         constexpr int i = decltype(Ic)::value;
         constexpr int S = chunk_src<BWD>(L, i), cc = chunk_cc<BWD>(L, i);
         constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
-        const bf16x8* sx = lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
+        return lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
+      };
+      {
+        const bf16x8* sx = row_base(std::integral_constant<int, 0>{}, 0);
+        constexpr int S0 = chunk_src<BWD>(L, 0);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-          for (int rg = 0; rg < RW; ++rg) dst[dx][rg] = sx[ps[S][rg] + dx];
-      };
-      read_row(std::integral_constant<int, 0>{}, 0, xf[0]);
+          for (int rg = 0; rg < RW; ++rg) xf[0][dx][rg] = sx[ps[S0][rg] + dx];
+      }
       static_for<NC>([&](auto Ic) {
         constexpr int i = decltype(Ic)::value;
         constexpr int n = layer_chunk0(L) + i;
@@ -343,10 +352,15 @@ struct Tile {
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int cur = (3 * i + dy) & 1;
-          if (dy < 2) read_row(Ic, dy + 1, xf[cur ^ 1]);
-          else if constexpr (i + 1 < NC) read_row(std::integral_constant<int, i + 1>{}, 0, xf[cur ^ 1]);
+          // the row after this one: row dy + 1 of this chunk, or row 0 of the next chunk
+          constexpr int inext = i + 1 < NC ? i + 1 : i;
+          const bool more = dy < 2 || i + 1 < NC;
+          const bf16x8* sxn = dy < 2 ? row_base(Ic, dy + 1) : row_base(std::integral_constant<int, inext>{}, 0);
+          const int* psn = dy < 2 ? ps[chunk_src<BWD>(L, i)] : ps[chunk_src<BWD>(L, inext)];
+          auto& dst = xf[cur ^ 1];
           __builtin_amdgcn_sched_barrier(0);
-          row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc);
+          row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc,
+                          [&](int dx, int rg) { if (more) dst[dx][rg] = sxn[psn[rg] + dx]; });
           __builtin_amdgcn_sched_barrier(0);
         }
       });
