@@ -358,6 +358,13 @@ struct Tile {
           const bf16x8* sxn = dy < 2 ? row_base(Ic, dy + 1) : row_base(std::integral_constant<int, inext>{}, 0);
           const int* psn = dy < 2 ? ps[chunk_src<BWD>(L, i)] : ps[chunk_src<BWD>(L, inext)];
           auto& dst = xf[cur ^ 1];
+          // Forward: the slice the layer before this one produced is the LAST source of this layer, so
+          // the waves do not meet at the end of a layer but here, in front of the first fragment read
+          // of that slice (issued behind the MFMAs of this row): by now every wave has long left its
+          // epilogue, and nobody waits.  (Backward reads the newest slice first: barrier at layer end.)
+          if constexpr (!BWD && L > 0 && i == NC - 3) {
+            if (dy == 2) __builtin_amdgcn_s_barrier();
+          }
           __builtin_amdgcn_sched_barrier(0);
           row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc,
                           [&](int dx, int rg) { if (more) dst[dx][rg] = sxn[psn[rg] + dx]; });
@@ -415,9 +422,9 @@ struct Tile {
             }
           }
         }
-        // the next layer reads what every wave has just written
+        // the next layer reads what every wave has just written (forward: the barrier comes later)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (BWD) __builtin_amdgcn_s_barrier();
         stamp();
       } else {
         // last layer: alpha * y + beta1 * (the kernel's input) + beta2 * res2 for this wave's 32 channels
