@@ -248,9 +248,17 @@ struct Tile {
     bf16x8* const ldsw = reinterpret_cast<bf16x8*>(smem);
     const float* const lbias = reinterpret_cast<const float*>(smem + BIAS_BASE);
 
+    // Per-layer state of a wave (accumulators, the pixels of its groups), kept in two alternating sets:
+    // the forward pass finishes layer L - 1's epilogue under the first MFMAs of layer L (below).
+    f32x16 accs[2][3];
+    int pys[2][3], pxs[2][3], pps[2][3];
+    bool lvs[2] = {true, true};
+
     static_for<5>([&](auto Lc) {
       constexpr int L = decltype(Lc)::value;
       constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
+      constexpr int P = L & 1;
+      static_assert(RW <= 3, "state arrays");
 #ifdef RDB_ABLATE_LAYERS
       if (L >= RDB_ABLATE_LAYERS) return;         // timing-only build: the first layers alone
 #endif
@@ -259,7 +267,8 @@ struct Tile {
       // the group set the layer's length anyway); layer 4: the pair of groups 2 * pair5 + rg.
       const int wsel = (wave_u + wave_rot(L)) & 3;
       const bool last_valid = L == 4 || (RW - 1) * 4 + wsel < NG;          // wave-uniform
-      int py[RW], px[RW], pp[RW];
+      lvs[P] = last_valid;
+      int (&py)[3] = pys[P], (&px)[3] = pxs[P], (&pp)[3] = pps[P];
 #pragma unroll
       for (int rg = 0; rg < RW; ++rg) {
         pp[rg] = (L == 4 ? pair5 * (NG5 / 2) + rg : rg * 4 + wsel) * 32 + pl;
@@ -300,7 +309,7 @@ struct Tile {
         }
       }
 
-      f32x16 acc[RW];
+      f32x16 (&acc)[3] = accs[P];
       if constexpr (BWD) {
 #pragma unroll
         for (int rg = 0; rg < RW; ++rg)
@@ -316,6 +325,63 @@ struct Tile {
             acc[rg][i] = b0[i]; acc[rg][4 + i] = b1[i]; acc[rg][8 + i] = b2[i]; acc[rg][12 + i] = b3[i];
           }
       }
+      // Forward: the epilogue of the layer before this one (LeakyReLU, bf16, into LDS and to the block
+      // buffer) is straight VALU work, about a thousand cycles in which the matrix pipe would idle.
+      // Its results are this layer's LAST source, so it runs in steps of four VALU instructions
+      // behind the first MFMAs of this layer, one step per MFMA (an MFMA gap of 32 cycles hides about
+      // five 4-cycle instructions, the fragment read included): accumulator reads / multiplies / maxima
+      // in halves, pack, zero, store for each (group, octet) of the previous layer.
+      constexpr bool DEFER = !BWD && L > 0;
+      constexpr int Lp = L > 0 ? L - 1 : 0, Q = P ^ 1;
+      constexpr int RWp = DEFER ? rw_max(Lp) : 0, NSTEP = 18 * RWp;
+      [[maybe_unused]] int e_lds[3];
+      [[maybe_unused]] unsigned e_goff[3];
+      [[maybe_unused]] bool e_ok[3], e_img[3];
+      [[maybe_unused]] float ev[8], et[8];
+      if constexpr (DEFER) {
+        constexpr int OHp = out_halo(Lp), OPp = out_p(Lp);
+#pragma unroll
+        for (int rg = 0; rg < RWp; ++rg) {
+          const int qy = pys[Q][rg], qx = pxs[Q][rg];
+          const int gy = oy0 - OHp + qy, gx = ox0 - OHp + qx;
+          e_ok[rg] = (rg < RWp - 1 || lvs[Q]) && pps[Q][rg] < OPp;
+          e_img[rg] = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+          const bool own = e_ok[rg] && e_img[rg] && qy >= OHp && qy < OHp + TH && qx >= OHp && qx < OHp + TW;
+          e_lds[rg] = src_base(Lp + 1) + hh * OPp + pps[Q][rg];
+          e_goff[rg] = own ? (unsigned)(slice_plane<BWD>(Lp) + hh) * plane_b + (unsigned)(gy * W + gx) * 16u : OOB;
+        }
+      }
+      [[maybe_unused]] u32x4_ eow;
+      auto epi_step = [&](int s) {                    // s: a constant after unrolling
+        if constexpr (DEFER) {
+          if (s >= NSTEP) return;
+          constexpr int OPp = out_p(Lp);
+          const int piece = s / 9, sub = s % 9, rg = piece >> 1, j = piece & 1, h4 = (sub & 1) * 4;
+          if (sub < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ev[h4 + e] = accs[Q][rg][j * 8 + h4 + e];
+          } else if (sub < 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) et[h4 + e] = ev[h4 + e] * p.slope;
+          } else if (sub < 6) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %2" : "=v"(ev[h4 + e]) : "v"(ev[h4 + e]), "v"(et[h4 + e]));
+          } else if (sub == 6) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)ev[e];
+            eow = __builtin_bit_cast(u32x4_, o);
+          } else if (sub == 7) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) eow[k] = e_img[rg] ? eow[k] : 0u;
+          } else {
+            if (e_ok[rg]) ldsw[e_lds[rg] + 2 * j * OPp] = __builtin_bit_cast(bf16x8, eow);
+            if constexpr (STORE)
+              __builtin_amdgcn_raw_buffer_store_b128(eow, grsrc, e_goff[rg] == OOB ? OOB : e_goff[rg] + (unsigned)(2 * j) * plane_b, 0, 0);
+          }
+        }
+      };
+
       // K loop: 16 channels a step, sources in the channel order of the buffer.  The activation
       // fragments of a tap row are read while the row before it is multiplied, across chunk boundaries
       // too: with one wave per SIMD nothing else hides the LDS latency.
@@ -363,18 +429,28 @@ struct Tile {
           // of that slice (issued behind the MFMAs of this row): by now every wave has long left its
           // epilogue, and nobody waits.  (Backward reads the newest slice first: barrier at layer end.)
           if constexpr (!BWD && L > 0 && i == NC - 3) {
-            if (dy == 2) __builtin_amdgcn_s_barrier();
+            if (dy == 2) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's slice is in LDS ...
+              __builtin_amdgcn_s_barrier();                             // ... and every other wave's
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           row_mma<RW, PF>(wbuf[n % (WDEPTH + 1)], wbuf[NB_], wrsrc, wlane, noff, dy, xf[cur], acc,
-                          [&](int dx, int rg) { if (more) dst[dx][rg] = sxn[psn[rg] + dx]; });
+                          [&](int dx, int rg) {
+                            if (more) dst[dx][rg] = sxn[psn[rg] + dx];
+                            epi_step(((i * 3 + dy) * 3 + dx) * RW + rg);
+                          });
           __builtin_amdgcn_sched_barrier(0);
         }
       });
 
       stamp();
-      if constexpr (L < 4) {
-        // forward: bias is in the accumulators, LeakyReLU; backward: times LeakyReLU'(x_j).  Zero outside
+      if constexpr (L < 4 && !BWD) {
+        // (its 18 steps per group must be done before the next layer's barrier, in chunk NC - 3 of that layer)
+        static_assert(18 * RW <= 9 * rw_max(L + 1) * (layer_nchunks(L + 1) - 3), "room for the deferred epilogue");
+        stamp();
+      } else if constexpr (L < 4) {
+        // backward: times LeakyReLU'(x_j) (the forward pass does this step under the next layer).  Zero outside
         // the image (the next layer's padding); into LDS for the layers behind, and the tile's own
         // pixels to the buffer (the backward pass / the weight gradients read them)
 #pragma unroll
