@@ -26,8 +26,11 @@ for d in dirs:
                     nums = re.findall(r"Li(\d+)E", m2.group(3))
                     k = m2.group(1) + "<" + ("bf16" if m2.group(2) == "DF16b" else "float") + "," + ",".join(nums) + ">"
                 else:
+                    m4 = re.search(r"rdb_kernel<(true|false)", name)
                     m3 = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
-                    k = m3.group(1) if m3 else name[:60]
+                    # the fused dense-block kernel under bench.py's names for its two directions
+                    k = ("rdb_bwd_kernel" if m4.group(1) == "true" else "rdb_fwd_kernel") if m4 else \
+                        (m3.group(1) if m3 else name[:60])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 res = {}
 for k, dd in agg.items():
@@ -40,6 +43,6 @@ for k, dd in agg.items():
     res[k] = e
 top = dict(sorted(res.items(), key=lambda kv: -kv[1].get("fetch_bytes", 0) * kv[1]["launches_seen"])[:10])
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum, one pass each, over "
-           "`python3 bench.py --no-cpu-baseline --no-profile --steps 2 --warmup 1`; per-launch means; FETCH_SIZE (KB) x2 "
+           "`python3 bench.py --no-cpu-baseline --no-profile --extras 0 --steps 2 --warmup 1`; per-launch means; FETCH_SIZE (KB) x2 "
            "per the gfx950 correction, WRITE_SIZE (KB) as read", "kernels": top}, open(out, "w"), indent=1)
 print(json.dumps(top, indent=1)[:1500])
