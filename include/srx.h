@@ -139,7 +139,9 @@ typedef struct srx_rdb_desc {
   int32_t nf, gc;        /* 64, 32                                                     */
   int32_t store_growth;  /* 1: x1..x4 written to buf planes [nf/8, (nf+4gc)/8)           */
   int32_t tile;          /* output tile per workgroup: 0 = 16 x 8 pixels, 1 = 8 x 8 (twice the
-                          * workgroups for a small feature map, a fifth more arithmetic)  */
+                          * workgroups for a small feature map, a fifth more arithmetic),
+                          * 2 = two 16 x 8 tiles stacked vertically, computed one after the
+                          * other from one staged input region (half the workgroups)      */
   void* buf; int64_t buf_img_stride;
   void* y;   int64_t y_img_stride;
   const void* w;

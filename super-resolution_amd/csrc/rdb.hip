@@ -59,7 +59,7 @@ struct RdbParams {
   float slope, alpha, beta1, beta2;
   int H, W, tiles_x, tiles_y, total;
 #ifdef RDB_STAMPS
-  unsigned long long* stamps;       // timing build: shader-clock stamps of workgroup 0 ([wave][16])
+  unsigned long long* stamps;       // timing build: shader-clock stamps of workgroup 8 ([wave][32], 256 values)
 #endif
 };
 
@@ -127,23 +127,28 @@ constexpr int mask_plane(int L) { return 8 + 4 * (3 - L); }
 // Geometry of a TW x TH-pixel output tile (TW * TH = 64 or 128 pixels) and the kernel body for it.
 // The 16 x 8 tile recomputes 1.5 x the arithmetic of the layer-by-layer form in its halos and needs
 // 132 KB of LDS; the 8 x 8 tile recomputes 1.85 x and needs 87 KB, and gives a small feature map
-// twice the workgroups.
-template <int TW, int TH>
+// twice the workgroups.  NH > 1: a workgroup computes NH tiles stacked vertically one after the
+// other from ONE staged input region (TH * NH + 10 rows): a feature map of two rounds of 16 x 8 tiles
+// becomes one round of workgroups that stage 28 % fewer bytes and wait for them once (155 KB of LDS).
+template <int TW, int TH, int NH = 1>
 struct Tile {
   static constexpr int reg_h(int halo) { return TH + 2 * halo; }
   static constexpr int reg_w(int halo) { return TW + 2 * halo; }
   static constexpr int reg_p(int halo) { return reg_h(halo) * reg_w(halo); }
+  static constexpr int X_P = (TH * NH + 2 * HALO) * reg_w(HALO);      // pixels of the staged input region
+  // pixels per plane of source s (the input region covers all NH tiles, the slices one tile)
+  static constexpr int src_p(int s) { return s == 0 ? X_P : reg_p(HALO - s); }
   // source s of a layer's input: 0 = block input (8 octet planes, halo 5); s = 1..4 = growth slice s
   // (4 planes, halo 5 - s).  Regions are stored [plane][pixel of the region], 16-byte slots.
   static constexpr int src_halo(int s) { return HALO - s; }
   static constexpr int src_planes(int s) { return s == 0 ? 8 : 4; }
-  static constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * reg_p(src_halo(s - 1)); }
-  static constexpr int ACT_SLOTS = 8 * reg_p(5) + 4 * (reg_p(4) + reg_p(3) + reg_p(2) + reg_p(1));
+  static constexpr int src_base(int s) { return s == 0 ? 0 : src_base(s - 1) + src_planes(s - 1) * src_p(s - 1); }
+  static constexpr int ACT_SLOTS = 8 * X_P + 4 * (reg_p(4) + reg_p(3) + reg_p(2) + reg_p(1));
   static constexpr int BIAS_BASE = ACT_SLOTS;              // packed biases: 4 x 32 + 64 floats = 48 slots
   static constexpr int LDS_SLOTS = BIAS_BASE + 64;
   static constexpr int LDS_BYTES = LDS_SLOTS * 16;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static constexpr int X_SLOTS = 8 * reg_p(HALO);
+  static constexpr int X_SLOTS = 8 * X_P;
   static constexpr int X_DMA = (X_SLOTS + 255) / 256;           // staging instructions per wave for x
   // layer L = 0..4 (conv1..conv5): output halo, pixel groups of 32, groups per wave
   static constexpr int out_halo(int L) { return L < 4 ? HALO - 1 - L : 0; }
@@ -165,7 +170,7 @@ struct Tile {
     int stamp_k = 0;
     auto stamp = [&]() {
       const unsigned long long tnow = __builtin_readcyclecounter();
-      if (blockIdx.x == 8 && lane == 0 && p.stamps) p.stamps[wave_u * 16 + stamp_k] = tnow;
+      if (blockIdx.x == 8 && lane == 0 && p.stamps && stamp_k < 32) p.stamps[wave_u * 32 + stamp_k] = tnow;
       ++stamp_k;
     };
     stamp();
@@ -183,7 +188,7 @@ struct Tile {
     const int tx = (int)(t % (unsigned)p.tiles_x);
     const unsigned tr = t / (unsigned)p.tiles_x;
     const int ty = (int)(tr % (unsigned)p.tiles_y), b = (int)(tr / (unsigned)p.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy_wg = ty * TH * NH, ox0 = tx * TW;
     const int H = p.H, W = p.W;
     const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;          // bytes of one octet plane
 
@@ -205,9 +210,9 @@ struct Tile {
 #pragma unroll
     for (int j = 0; j < X_DMA; ++j) {
       const unsigned slot = (unsigned)(j * 256 + tid);
-      const unsigned q = slot / (unsigned)reg_p(HALO), pix = slot - q * (unsigned)reg_p(HALO);
+      const unsigned q = slot / (unsigned)X_P, pix = slot - q * (unsigned)X_P;
       const unsigned r = pix / (unsigned)reg_w(HALO), c = pix - r * (unsigned)reg_w(HALO);
-      const int gy = oy0 - HALO + (int)r, gx = ox0 - HALO + (int)c;
+      const int gy = oy_wg - HALO + (int)r, gx = ox0 - HALO + (int)c;
       const bool ok = (slot < (unsigned)X_SLOTS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
       const unsigned off = q * plane_b + (unsigned)(gy * W + gx) * 16u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + j * 256 + wave_u * 64), 16, ok ? off : OOB, 0, 0, 0);
@@ -224,6 +229,7 @@ struct Tile {
     constexpr int WDEPTH = 3;                  // chunks in flight ahead of the multiply (L2 latency under load: about 1 us)
     u32x4_ wbuf[WDEPTH + 1][9];
     auto chunk_bytes = [&](int n) -> unsigned {          // n: compile-time after unrolling
+      if (NH > 1 && n >= NCHUNK_WAVE) n -= NCHUNK_WAVE;    // the next tile's first chunks
       return n < layer_chunk0(4) ? (unsigned)n * WCHUNK_BYTES : (unsigned)(n + 12 * pass5) * WCHUNK_BYTES;
     };
     auto load_w = [&](int n, u32x4_ (&dst)[9]) {
@@ -253,7 +259,13 @@ struct Tile {
     f32x16 accs[2][3];
     int pys[2][3], pxs[2][3], pps[2][3];
     bool lvs[2] = {true, true};
+    static_assert(NCHUNK_WAVE % (WDEPTH + 1) == 0, "the weight ring keeps its phase from tile to tile");
 
+    // the NH tiles of this workgroup, top to bottom (a run-time loop: the layer code exists once)
+#pragma clang loop unroll(disable)
+    for (int half = 0; half < NH; ++half) {
+    const int oy0 = oy_wg + half * TH;
+    const int xoff = half * TH * reg_w(HALO);           // the tile's first row inside the staged input region
     static_for<5>([&](auto Lc) {
       constexpr int L = decltype(Lc)::value;
       constexpr int OH_ = out_halo(L), OWd = reg_w(OH_), OP = out_p(L), NG = out_groups(L), RW = rw_max(L);
@@ -398,8 +410,8 @@ struct Tile {
       auto row_base = [&](auto Ic, int dy) -> const bf16x8* {
         constexpr int i = decltype(Ic)::value;
         constexpr int S = chunk_src<BWD>(L, i), cc = chunk_cc<BWD>(L, i);
-        constexpr int SW = reg_w(src_halo(S)), SP = reg_p(src_halo(S));
-        return lds + src_base(S) + (2 * cc + hh) * SP + dy * SW;
+        constexpr int SW = reg_w(src_halo(S)), SP = src_p(S);
+        return lds + src_base(S) + (2 * cc + hh) * SP + dy * SW + (S == 0 ? xoff : 0);
       };
       {
         const bf16x8* sx = row_base(std::integral_constant<int, 0>{}, 0);
@@ -412,7 +424,7 @@ struct Tile {
       static_for<NC>([&](auto Ic) {
         constexpr int i = decltype(Ic)::value;
         constexpr int n = layer_chunk0(L) + i;
-        constexpr bool PF = n + WDEPTH < NCHUNK_WAVE;
+        constexpr bool PF = NH > 1 || n + WDEPTH < NCHUNK_WAVE;
         constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
         const unsigned noff = chunk_bytes(n + WDEPTH);
 #pragma unroll
@@ -513,7 +525,7 @@ struct Tile {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int oct = pass5 * 4 + 2 * j + hh;
-            const bf16x8 xr = lds[src_base(0) + oct * reg_p(HALO) + xs];
+            const bf16x8 xr = lds[src_base(0) + oct * X_P + xs + xoff];
             const float b1 = p.beta1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[rg][j * 8 + e] += b1 * (float)xr[e];
@@ -540,13 +552,19 @@ struct Tile {
         stamp();
       }
     });
+    // the next tile's first layers write the slice regions this tile's last layer may still be reading
+    if (NH > 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    }
   }
 };
 
-template <bool BWD, bool STORE, int TW, int TH>
+template <bool BWD, bool STORE, int TW, int TH, int NH>
 __global__ __launch_bounds__(256, 1) void rdb_kernel(const RdbParams p) {
   extern __shared__ __attribute__((aligned(16))) u32x4_ smem[];
-  Tile<TW, TH>::template run<BWD, STORE>(p, smem);
+  Tile<TW, TH, NH>::template run<BWD, STORE>(p, smem);
 }
 
 }  // namespace
@@ -556,16 +574,16 @@ static unsigned long long* g_rdb_stamps = nullptr;
 extern "C" void srx_rdb_debug_stamps(void* buf) { g_rdb_stamps = static_cast<unsigned long long*>(buf); }
 #endif
 
-template <bool BWD, bool STORE, int TW, int TH>
+template <bool BWD, bool STORE, int TW, int TH, int NH>
 static int rdb_launch_tile(RdbParams p, const srx_rdb_desc* d, hipStream_t s, const char* who) {
-  constexpr int LDS_BYTES = Tile<TW, TH>::LDS_BYTES;
+  constexpr int LDS_BYTES = Tile<TW, TH, NH>::LDS_BYTES;
   p.tiles_x = (d->W + TW - 1) / TW;
-  p.tiles_y = (d->H + TH - 1) / TH;
+  p.tiles_y = (d->H + TH * NH - 1) / (TH * NH);
   const long total = (long)p.tiles_x * p.tiles_y * d->B;
   SRX_CHECK_ARG(total < (1L << 31), "%s: grid out of range", who);
   p.total = (int)total;
   static srx_per_device_once attr;         // per instantiation, per device
-  auto kern = rdb_kernel<BWD, STORE, TW, TH>;
+  auto kern = rdb_kernel<BWD, STORE, TW, TH, NH>;
   if (int rc = srx_ensure_dynamic_lds(&attr, reinterpret_cast<const void*>(kern), LDS_BYTES)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), LDS_BYTES, s, p);
   return srx_check_launch(BWD ? "rdb_kernel (backward)" : "rdb_kernel (forward)");
@@ -592,18 +610,23 @@ static int rdb_launch(const srx_rdb_desc* d, void* stream, bool bwd, const char*
   p.act = static_cast<const bf16*>(d->act); p.act_is = d->act_img_stride;
   p.slope = d->act_slope; p.alpha = d->alpha; p.beta1 = d->beta1; p.beta2 = d->beta2;
   p.H = d->H; p.W = d->W;
-  SRX_CHECK_ARG(d->tile == 0 || d->tile == 1, "%s: tile must be 0 (16 x 8) or 1 (8 x 8), got %d", who, d->tile);
+  SRX_CHECK_ARG(d->tile >= 0 && d->tile <= 2, "%s: tile must be 0 (16 x 8), 1 (8 x 8) or 2 (16 x 8, two per workgroup), got %d",
+                who, d->tile);
 #ifdef RDB_STAMPS
   p.stamps = g_rdb_stamps;
 #endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mode = bwd ? 2 : (d->store_growth ? 1 : 0);
   if (d->tile == 0) {
-    if (mode == 2) return rdb_launch_tile<true, true, 16, 8>(p, d, s, who);
-    return mode == 1 ? rdb_launch_tile<false, true, 16, 8>(p, d, s, who) : rdb_launch_tile<false, false, 16, 8>(p, d, s, who);
+    if (mode == 2) return rdb_launch_tile<true, true, 16, 8, 1>(p, d, s, who);
+    return mode == 1 ? rdb_launch_tile<false, true, 16, 8, 1>(p, d, s, who) : rdb_launch_tile<false, false, 16, 8, 1>(p, d, s, who);
   }
-  if (mode == 2) return rdb_launch_tile<true, true, 8, 8>(p, d, s, who);
-  return mode == 1 ? rdb_launch_tile<false, true, 8, 8>(p, d, s, who) : rdb_launch_tile<false, false, 8, 8>(p, d, s, who);
+  if (d->tile == 2) {
+    if (mode == 2) return rdb_launch_tile<true, true, 16, 8, 2>(p, d, s, who);
+    return mode == 1 ? rdb_launch_tile<false, true, 16, 8, 2>(p, d, s, who) : rdb_launch_tile<false, false, 16, 8, 2>(p, d, s, who);
+  }
+  if (mode == 2) return rdb_launch_tile<true, true, 8, 8, 1>(p, d, s, who);
+  return mode == 1 ? rdb_launch_tile<false, true, 8, 8, 1>(p, d, s, who) : rdb_launch_tile<false, false, 8, 8, 1>(p, d, s, who);
 }
 
 extern "C" int srx_rdb_forward(const srx_rdb_desc* d, void* stream) { return rdb_launch(d, stream, false, "srx_rdb_forward"); }

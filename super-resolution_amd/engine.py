@@ -686,14 +686,18 @@ class _GenBase(Plan):
     # the side stream (weight gradients in backward; the discriminator / VGG passes on the real batch
     # beside the generator's forward in the adversarial step) runs on the CUs the larger tiles leave
     # free (config 3, A/B on one box: 7.84 ms per step with 16 x 8 in both passes, 8.00 with 8 x 8 in
-    # forward, 8.12 in both).  SRX_RDB_TILE_FWD / SRX_RDB_TILE_BWD = 0 / 1 force 16 x 8 / 8 x 8.
-    rdb_tile_fwd = {"0": 0, "1": 1}.get(os.environ.get("SRX_RDB_TILE_FWD", "auto"))
-    rdb_tile_bwd = {"0": 0, "1": 1}.get(os.environ.get("SRX_RDB_TILE_BWD", "auto"))
+    # forward, 8.12 in both).  SRX_RDB_TILE_FWD / SRX_RDB_TILE_BWD = 0 / 1 / 2 force 16 x 8 / 8 x 8 / two stacked 16 x 8.
+    rdb_tile_fwd = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("SRX_RDB_TILE_FWD", "auto"))
+    rdb_tile_bwd = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("SRX_RDB_TILE_BWD", "auto"))
 
     def rdb_tile(self, B: int, h: int, w: int, backward: bool) -> int:
+        """srx_rdb_desc.tile: 0 = 16 x 8 pixels per workgroup, 1 = 8 x 8, 2 = two 16 x 8 tiles stacked
+        vertically per workgroup (one staged input region for both)."""
         forced = self.rdb_tile_bwd if backward else self.rdb_tile_fwd
         if forced is not None:
             return forced
+        if B * _ceil(h, 8) * _ceil(w, 16) > 256:
+            return 2            # more 16 x 8 tiles than CUs: one round of two-tile workgroups instead of two rounds
         if backward or self.need_grad:
             return 0
         return 1 if B * _ceil(h, 8) * _ceil(w, 8) <= 256 else 0

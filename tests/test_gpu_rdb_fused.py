@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def _plans(shape, need_grad, num_blocks=2, fused_bwd=False, tile=0):
     """(layer-by-layer plan, plan with the fused forward [and the fused data gradient]) on 16 x 8
-    (tile 0) or 8 x 8 (tile 1) pixel tiles"""
+    (tile 0), 8 x 8 (tile 1) or two stacked 16 x 8 (tile 2) pixel tiles"""
     E, G = pkg("engine"), pkg("esrgan.generator")
     g = fill_module_(G.GeneratorESRGAN(num_blocks=num_blocks), salt=51).cuda()
     params = {n: p.data for n, p in g.named_parameters()}
@@ -35,7 +35,7 @@ def _plans(shape, need_grad, num_blocks=2, fused_bwd=False, tile=0):
     return out
 
 
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("need_grad", [True, False])
 @pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
 def test_fused_block_forward_equals_layer_by_layer(shape, need_grad, tile):
@@ -72,7 +72,7 @@ def test_fused_block_backward_uses_the_stored_growth_slices():
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
 
 
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(2, 20, 28), (1, 37, 53), (3, 64, 64), (2, 5, 9), (1, 8, 16), (2, 16, 8)])
 def test_fused_block_data_gradient_equals_layer_by_layer(shape, tile):
     """srx_rdb_backward against the five data-gradient launches: every gradient buffer
@@ -107,7 +107,7 @@ def test_fused_block_rejects_what_it_does_not_cover():
     d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32)
     assert lib.srx_rdb_backward(d, None) == 1 and b"null buf" in lib.srx_last_error()
     assert lib.srx_rdb_backward(None, None) == 1
-    d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32, tile=2, buf=256, y=256, w=256, bias=256)
+    d = L.RdbDesc(dtype=L.BF16, B=1, H=8, W=8, nf=64, gc=32, tile=3, buf=256, y=256, w=256, bias=256)
     assert lib.srx_rdb_forward(d, None) == 1 and b"tile must be" in lib.srx_last_error()
 
 

@@ -17,9 +17,10 @@ params = {n: p.data for n, p in g.named_parameters()}
 plan = E.GeneratorPlan(params, B, H, W, torch.bfloat16, num_blocks=2, need_grad=True)
 x = torch.rand(B, 3, H, W, device=dev) * 2 - 1
 gy = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+buf = torch.zeros(4 * 32, dtype=torch.int64, device=dev)      # the kernel writes [wave][32]
 names = ["staged"] + [f"L{l}{s}" for l in range(5) for s in (" loop", " epi")]
 for phase in ("forward", "backward"):
+    buf.zero_()
     for rep in range(3):
         lib.srx_rdb_debug_stamps(None)
         plan.forward(x)
@@ -31,8 +32,9 @@ for phase in ("forward", "backward"):
             plan.forward(x)
         torch.cuda.synchronize()
     lib.srx_rdb_debug_stamps(None)
-    t = buf.cpu().view(4, 16)
+    t = buf.cpu().view(4, 32)
     print(phase, "(last fused launch, workgroup 8): cycles since kernel start, per wave")
-    for k, nm in enumerate(names):
-        print(f"  {nm:8s}", *[f"{int(t[w, k + 1] - t[w, 0]):8d}" for w in range(4)],
+    allnames = names + ([n + " (2nd tile)" for n in names[1:]] if int(t[0, len(names) + 1]) > 0 else [])
+    for k, nm in enumerate(allnames):
+        print(f"  {nm:18s}", *[f"{int(t[w, k + 1] - t[w, 0]):8d}" for w in range(4)],
               "   delta", *[f"{int(t[w, k + 1] - t[w, k]):7d}" for w in range(4)])
