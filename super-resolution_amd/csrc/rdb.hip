@@ -424,6 +424,9 @@ struct Tile {
       static_for<NC>([&](auto Ic) {
         constexpr int i = decltype(Ic)::value;
         constexpr int n = layer_chunk0(L) + i;
+#ifdef RDB_STAMPS_L0
+        if constexpr (L == 0) stamp();               // timing build: a stamp in front of every chunk of the first layer
+#endif
         constexpr bool PF = NH > 1 || n + WDEPTH < NCHUNK_WAVE;
         constexpr int NB_ = (n + WDEPTH) % (WDEPTH + 1);
         const unsigned noff = chunk_bytes(n + WDEPTH);
