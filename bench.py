@@ -391,6 +391,7 @@ def main():
     ap.add_argument("--skip-wgrad", action="store_true", help="diagnostic: drop weight-gradient launches (INVALID as a result)")
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
+    ap.add_argument("--wgrad-target-wgs", type=int, default=None, help="workgroups a trunk weight-gradient launch aims for")
     ap.add_argument("--pair-wgrad-tasks", type=int, default=0,
                     help="pair the dense blocks' single-sub-block weight-gradient tasks (0/1)")
     ap.add_argument("--wgrad-walk-last", type=int, default=None,
@@ -472,6 +473,8 @@ def main():
         E.GeneratorPlan.trunk_wgrad_slices = args.wgrad_slices
     if args.wgrad_walk_last is not None:
         E.GeneratorPlan.trunk_wgrad_walk_last = args.wgrad_walk_last
+    if args.wgrad_target_wgs is not None:
+        E.GeneratorPlan.trunk_wgrad_target_wgs = args.wgrad_target_wgs
     if args.wgrad_rdbs is not None:
         E.GeneratorPlan.trunk_wgrad_rdbs = args.wgrad_rdbs
     if adv:

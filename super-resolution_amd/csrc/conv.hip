@@ -574,6 +574,16 @@ static int forced_waves() {
 template <typename T>
 int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
   const bool nb2 = (p.nblk % 2) == 0;
+  // Small feature maps (16 x 8 and 8 x 16-pixel tiles): 64 output channels per workgroup only while
+  // that gives every CU a workgroup; otherwise 32, twice the workgroups (SRX_CONV_SMALL_NB1=0: always 64)
+  auto nb2s = [&](int ltw) {
+    if (!nb2) return false;
+    static const bool off = [] { const char* e = getenv("SRX_CONV_SMALL_NB1"); return e && atoi(e) == 0; }();
+    if (off) return true;
+    const int tw = 1 << ltw, th = 4 * (32 >> ltw);
+    const long wgs = (long)((p.OW + tw - 1) / tw) * ((p.OH + th - 1) / th) * d->B * (p.nblk / 2);
+    return wgs >= 256;
+  };
   if (d->ksize == 1) {
     return nb2 ? launch<T, 1, 2, 1, 5, 1>(p, d->B, s) : launch<T, 1, 1, 1, 5, 1>(p, d->B, s);
   }
@@ -592,12 +602,12 @@ int dispatch(const srx_conv_desc* d, const ConvParams& p, hipStream_t s) {
       if (wgs8 < 256) return nb2 ? launch<T, 1, 2, 1, 5, 3>(p, d->B, s) : launch<T, 1, 1, 1, 5, 3>(p, d->B, s);
       return nb2 ? launch<T, 1, 2, 2, 5, 3>(p, d->B, s) : launch<T, 1, 1, 2, 5, 3>(p, d->B, s);
     }
-    if (p.OW >= 12) return nb2 ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);
-    return nb2 ? launch<T, 1, 2, 1, 3, 3>(p, d->B, s) : launch<T, 1, 1, 1, 3, 3>(p, d->B, s);
+    if (p.OW >= 12) return nb2s(4) ? launch<T, 1, 2, 1, 4, 3>(p, d->B, s) : launch<T, 1, 1, 1, 4, 3>(p, d->B, s);
+    return nb2s(3) ? launch<T, 1, 2, 1, 3, 3>(p, d->B, s) : launch<T, 1, 1, 1, 3, 3>(p, d->B, s);
   }
   if (p.OW >= 24) return nb2 ? launch<T, 2, 2, 1, 5, 3>(p, d->B, s) : launch<T, 2, 1, 1, 5, 3>(p, d->B, s);
-  if (p.OW >= 12) return nb2 ? launch<T, 2, 2, 1, 4, 3>(p, d->B, s) : launch<T, 2, 1, 1, 4, 3>(p, d->B, s);
-  return nb2 ? launch<T, 2, 2, 1, 3, 3>(p, d->B, s) : launch<T, 2, 1, 1, 3, 3>(p, d->B, s);
+  if (p.OW >= 12) return nb2s(4) ? launch<T, 2, 2, 1, 4, 3>(p, d->B, s) : launch<T, 2, 1, 1, 4, 3>(p, d->B, s);
+  return nb2s(3) ? launch<T, 2, 2, 1, 3, 3>(p, d->B, s) : launch<T, 2, 1, 1, 3, 3>(p, d->B, s);
 }
 
 }  // namespace

@@ -111,6 +111,13 @@ def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: i
     """Mirror of the instantiation choice in csrc/conv.hip (dispatch<T>)."""
     t = "bf16" if dt == L.BF16 else "float"
     nb = 2 if (_ceil(cout, 32) % 2 == 0) else 1
+
+    def nb_small(ltw: int) -> int:
+        tw, th = 1 << ltw, 4 * (32 >> ltw)
+        if nb == 2 and os.environ.get("SRX_CONV_SMALL_NB1", "1") != "0" and \
+                _ceil(OW, tw) * _ceil(OH, th) * B * (_ceil(cout, 32) // 2) < 256:
+            return 1
+        return nb
     if ksize == 1:
         cfg = (1, nb, 1, 5, 1)
     elif stride == 1:
@@ -118,11 +125,14 @@ def conv_kernel_name(dt: int, ksize: int, stride: int, OH: int, OW: int, cout: i
             wgs8 = _ceil(OW, 32) * _ceil(OH, 8) * B * (_ceil(cout, 32) // nb)
             cfg = (1, 1, 4, 5, 3) if (OH * OW >= 128 * 128 and nb == 1) else (1, nb, 1 if wgs8 < 256 else 2, 5, 3)
         elif OW >= 12:
-            cfg = (1, nb, 1, 4, 3)
+            cfg = (1, nb_small(4), 1, 4, 3)
         else:
-            cfg = (1, nb, 1, 3, 3)
+            cfg = (1, nb_small(3), 1, 3, 3)
+    elif OW >= 24:
+        cfg = (2, nb, 1, 5, 3)
     else:
-        cfg = (2, nb, 1, 5 if OW >= 24 else (4 if OW >= 12 else 3), 3)
+        ltw = 4 if OW >= 12 else 3
+        cfg = (2, nb_small(ltw), 1, ltw, 3)
     return "conv_kernel<%s,%d,%d,%d,%d,%d>" % ((t,) + cfg)
 
 
@@ -903,8 +913,17 @@ class GeneratorPlan(_GenBase):
     """
 
     trunk_wgrad_slices = 4
+    trunk_wgrad_target_wgs = 256   # workgroups a trunk weight-gradient launch aims for (one per CU)
     overlap_wgrad = True        # weight gradients on a side stream, beside the data-gradient chain
-    trunk_wgrad_rdbs = 6        # dense blocks per weight-gradient launch in that mode (0: all in one)
+    # dense blocks per weight-gradient launch in that mode (0: all in one).  Re-measured with the fused
+    # forward in place, A/B on one box, config 2: 4 / 5 / 6 / 8 blocks 9.34 / 9.33 / 9.44 / 9.47 ms per step;
+    # 64 x 128 x 128: 122.4 with 5 against 122.9 with 6.
+    trunk_wgrad_rdbs = 5
+    # Beside the fused data gradient (one 132 KB workgroup per tile, which shares a CU with nothing) a
+    # weight-gradient launch should leave CUs free: about 130 workgroups instead of one per CU
+    # (config 3, one box: 7.57 ms per step with 250 workgroups per launch, 7.08 with 104-156).
+    fused_bwd_wgrad_slices = 2
+    fused_bwd_wgrad_target_wgs = 128
     # the last trunk weight-gradient launches run after the data-gradient chain has ended, alone on
     # the chip, where the column-walk kernel is the faster one (beside the chain it is the slower)
     # (None: by size — measured best: 2 launches at 64 K pixels per step, 8 from 256 K pixels on,
@@ -1061,7 +1080,10 @@ class GeneratorPlan(_GenBase):
             pending, pending_names, n_pending = [], [], 0
             per_block = len(tasks) // nblocks
             # enough pixel slices to give every CU a workgroup, at least the configured number
-            nsl = max(self.trunk_wgrad_slices, min(32, 256 // max(1, len(tasks))))
+            if self.use_fused_rdb_bwd(B, h, w, nf, gc):
+                nsl = max(self.fused_bwd_wgrad_slices, min(32, self.fused_bwd_wgrad_target_wgs // max(1, len(tasks))))
+            else:
+                nsl = max(self.trunk_wgrad_slices, min(32, self.trunk_wgrad_target_wgs // max(1, len(tasks))))
             launch_no += 1
             k_walk = self.trunk_wgrad_walk_last
             if k_walk is None:
