@@ -740,11 +740,24 @@ class _GenBase(Plan):
         wt = P[name + ".weight"]
         return self.packed_layer(cout_v, wt.shape[0], 9, 0, [dgrad_seg(wt, 0, 0)], with_bias=False)[0]
 
+    # Workgroups (tasks x pixel slices) of the weight-gradient launch of a single layer (the layers
+    # outside the dense blocks; in backward they run beside the data gradients of the HR-resolution
+    # layers, whose workgroups fill every CU twice over): few enough to leave those room.  A/B on one
+    # box, per step: config 2 9.56 ms at 512, 9.50 at 256, 9.08-9.16 at 128-160, 9.90 at 64; config 3 7.04
+    # at 512, 6.78 at 128; 64 x 128 x 128 (16 M pixels at HR resolution) 119.8 at 512, 121.7 at 128.
+    # SRX_LAYER_WGRAD_BLOCKS overrides both.
+    layer_wgrad_blocks_small, layer_wgrad_blocks_large = 160, 512
+    layer_wgrad_small_pixels = 1 << 21
+    _layer_wgrad_blocks_env = os.environ.get("SRX_LAYER_WGRAD_BLOCKS")
+
     def layer_wgrad(self, ops, P, name, x: View, gy: View, B, Hh, Ww):
         wt = P[name + ".weight"]
         tasks = self.wgrad_tasks_for_layer(wt.shape[1], wt.shape[0], 0, 0, self.sp(name + ".weight"),
                                            bias_ptr=self.sp(name + ".bias"))
-        self.wgrad(ops, x, gy, tasks, B, Hh, Ww)
+        blocks = (int(self._layer_wgrad_blocks_env) if self._layer_wgrad_blocks_env else
+                  self.layer_wgrad_blocks_small if B * Hh * Ww <= self.layer_wgrad_small_pixels
+                  else self.layer_wgrad_blocks_large)
+        self.wgrad(ops, x, gy, tasks, B, Hh, Ww, target_blocks=blocks)
 
     # ---- dense block ------------------------------------------------------
     def emit_rdb_fwd(self, ops, P, pre, cur: Buf, dst: View, B, h, w, nf, gc, q,
