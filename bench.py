@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--wgrad-slices", type=int, default=None, help="pixel slices per weight-gradient task")
     ap.add_argument("--wgrad-rdbs", type=int, default=None, help="dense blocks per weight-gradient launch")
     ap.add_argument("--wgrad-target-wgs", type=int, default=None, help="workgroups a trunk weight-gradient launch aims for")
+    ap.add_argument("--wgrad-tail", type=str, default=None, help="dense blocks of the last weight-gradient launches, e.g. 3,2,1")
     ap.add_argument("--pair-wgrad-tasks", type=int, default=0,
                     help="pair the dense blocks' single-sub-block weight-gradient tasks (0/1)")
     ap.add_argument("--wgrad-walk-last", type=int, default=None,
@@ -473,6 +474,8 @@ def main():
         E.GeneratorPlan.trunk_wgrad_slices = args.wgrad_slices
     if args.wgrad_walk_last is not None:
         E.GeneratorPlan.trunk_wgrad_walk_last = args.wgrad_walk_last
+    if args.wgrad_tail is not None:
+        E.GeneratorPlan.trunk_wgrad_tail = tuple(int(t) for t in args.wgrad_tail.split(","))
     if args.wgrad_target_wgs is not None:
         E.GeneratorPlan.trunk_wgrad_target_wgs = args.wgrad_target_wgs
     if args.wgrad_rdbs is not None:

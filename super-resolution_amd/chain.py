@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -57,6 +59,9 @@ class ChainPlan(Plan, _GradMixin):
          "stride": 1|2, "act": slope (1.0 = none), "scale_ptr": device float* (0 = none)}
         {"kind": "pool"} | {"kind": "gap"}
     """
+
+    # workgroups (tasks x pixel slices) a layer's weight-gradient launch aims for
+    wgrad_blocks = int(os.environ.get("SRX_CHAIN_WGRAD_BLOCKS", "512"))
 
     def __init__(self, layers: List[dict], B: int, C_in: int, H: int, W: int, tdtype, device, *,
                  need_param_grad: bool, need_input_grad: bool, final_slope: float = 1.0,
@@ -152,7 +157,7 @@ class ChainPlan(Plan, _GradMixin):
                             cin, cout, 0, 0, self.sp(ly["wname"]),
                             bias_ptr=self.sp(ly["bname"]) if ly.get("b") is not None else 0)
                         self.wgrad(bwd, (self.A[i - 1], 0), (self.gA[i], 0), tasks, b_i, h_i, w_i,
-                                   ksize=ks, stride=st)
+                                   ksize=ks, stride=st, target_blocks=self.wgrad_blocks)
                     if produce_input:
                         wp = self.packed_layer(cin, cout, ks * ks, 0,
                                                [dgrad_seg(wt, 0, 0, 1.0, ly.get("scale_ptr", 0))],

@@ -932,6 +932,7 @@ class GeneratorPlan(_GenBase):
     # forward in place, A/B on one box, config 2: 4 / 5 / 6 / 8 blocks 9.34 / 9.33 / 9.44 / 9.47 ms per step;
     # 64 x 128 x 128: 122.4 with 5 against 122.9 with 6.
     trunk_wgrad_rdbs = 5
+    trunk_wgrad_tail = (4, 3, 2)   # dense blocks of the last launches (they end after the chain: short ones)
     # Beside the fused data gradient (one 132 KB workgroup per tile, which shares a CU with nothing) a
     # weight-gradient launch should leave CUs free: about 130 workgroups instead of one per CU
     # (config 3, one box: 7.57 ms per step with 250 workgroups per launch, 7.08 with 104-156).
@@ -1066,7 +1067,7 @@ class GeneratorPlan(_GenBase):
         # the data-gradient chain has ended, with nothing to hide behind: they shrink (and take
         # more pixel slices, below) so that this tail is short.
         if self.overlap_wgrad and self.trunk_wgrad_rdbs > 0:
-            tail = [s_ for s_ in (4, 3, 2) if s_ < self.trunk_wgrad_rdbs]
+            tail = [s_ for s_ in self.trunk_wgrad_tail if s_ < self.trunk_wgrad_rdbs]
             sizes, left = [], nR
             while left > sum(tail) + self.trunk_wgrad_rdbs:
                 sizes.append(self.trunk_wgrad_rdbs)

@@ -10,6 +10,7 @@ the caller reads whenever it wants to log.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -305,7 +306,14 @@ class AdversarialTrainer:
         dbufs = {n: b for n, b in disc.named_buffers()}
         mk = lambda pg, ig: chain.DiscriminatorPlan(dparams, dbufs, B, H, W, compute_dtype,
                                                     need_param_grad=pg, need_input_grad=ig)
-        self.d_real, self.d_fake, self.d_gen = mk(True, False), mk(True, False), mk(False, True)
+        # Inside this step a discriminator pass always has another stream's launches beside it (the
+        # generator's forward pass, the perceptual branch): its weight-gradient launches take few
+        # workgroups, so that those find CUs (a fused dense-block workgroup shares a CU with nothing).
+        keep, chain.ChainPlan.wgrad_blocks = chain.ChainPlan.wgrad_blocks, self.disc_wgrad_blocks
+        try:
+            self.d_real, self.d_fake, self.d_gen = mk(True, False), mk(True, False), mk(False, True)
+        finally:
+            chain.ChainPlan.wgrad_blocks = keep
         vparams = {n: (p.data if p.dtype == torch.float32 else p.data.float())
                    for n, p in vgg_loss.vgg.named_parameters()}
         self._vparams = vparams
@@ -323,6 +331,12 @@ class AdversarialTrainer:
         engine.side_stream(dev)      # created here, not inside the first step
 
     step_in_backward = False    # as in GeneratorWarmupTrainer
+
+    # workgroups per weight-gradient launch of the discriminator plans (chain.ChainPlan.wgrad_blocks;
+    # 512 for a discriminator that runs alone).  A/B on one box, per step: HR 128 x 128 (config 3)
+    # 7.22 ms at 512, 6.60 at 256, 6.30 at 128, 6.25 at 96, 6.7 at 32; HR 256 x 256 16.4 at 512, 15.7 at 256,
+    # 15.5 at 192 and 128, 16.6 at 64.
+    disc_wgrad_blocks = int(os.environ.get("SRX_DISC_WGRAD_BLOCKS", "128"))
 
     # D(hr) pass and VGG(hr) features beside the generator forward, the perceptual branch beside
     # the discriminator step and the adversarial branch
