@@ -129,3 +129,10 @@ def test_fused_block_is_chosen_by_size():
     assert [m[0] for m in t128.bwd_meta].count("rdb_bwd_kernel") == 3
     assert [m[0] for m in t512.fwd_meta].count("rdb_fwd_kernel") == 3
     assert all(m[0] != "rdb_bwd_kernel" for m in t512.bwd_meta)
+    # tiles: training plans 16 x 8, stacked in pairs where there are more tiles than CUs; inference
+    # plans of small maps 8 x 8
+    L = pkg("_lib")
+    tile = lambda plan, ops, kind: [op.u.rdb.tile for op in ops if op.kind == kind]
+    assert set(tile(t128, t128.fwd_ops, L.OP_RDB_FWD)) == {0} and set(tile(t128, t128.bwd_ops, L.OP_RDB_BWD)) == {0}
+    assert set(tile(t512, t512.fwd_ops, L.OP_RDB_FWD)) == {2}
+    assert set(tile(small, small.fwd_ops, L.OP_RDB_FWD)) == {1}
