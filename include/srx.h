@@ -208,8 +208,8 @@ typedef struct srx_wgrad_desc {
                             buffers; used to co-locate them on one XCD (speed only)  */
   int32_t tile_walk;     /* 3x3 / stride-1 launches on images at least 24 pixels wide: 1 selects the
                             column-walk kernel (tiles walked down the image, input rows kept in an
-                            LDS ring: a third less activation staging; faster alone on the chip,
-                            slower beside a convolution chain); 0 the whole-halo-tile kernel     */
+                            LDS ring: a third less activation staging, the faster one alone on
+                            the chip and beside a convolution chain); 0 the whole-halo-tile kernel */
   int32_t pad_;
   int64_t slice_stride;  /* 0: the pixel slices of a task ADD into the same tensors with fp32 atomics
                             (the order of the adds, hence the last bits, varies from run to run).

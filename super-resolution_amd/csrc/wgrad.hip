@@ -625,7 +625,17 @@ __global__ __launch_bounds__(256) void wgrad_walk_kernel(const WgradParams p) {
     const int n = p.tiles_y - ty0 < left ? p.tiles_y - ty0 : left;     // tiles of this column in the slice
     // step j: group ty0+j has landed; stage group ty0+j+1 and the gradient tile of tile j; multiply
     // tile j-1.  The last step stages the first group of the slice's next column instead.
-    for (int j = 0; j <= n; ++j) {
+    // (step 0, which has nothing to multiply yet, stands in front of the loop: with the multiply
+    // under a condition on j the accumulators pass through copies at every step)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int nxt = ring == 2 ? 0 : ring + 1;
+      stage_group(b, tx, ty0 + 1, nxt);
+      stage_gy(b, tx, ty0, 0);
+      ring = nxt;
+    }
+    for (int j = 1; j <= n; ++j) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();        // landed in every wave; every wave is done with the slot staged next
       const int nxt = ring == 2 ? 0 : ring + 1;
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256) void wgrad_walk_kernel(const WgradParams p) {
         const int col2 = (t + n) / p.tiles_y;
         stage_group(col2 / p.tiles_x, col2 % p.tiles_x, (t + n) % p.tiles_y, nxt);
       }
-      if (j >= 1 && active) compute(ring == 0 ? 2 : ring - 1, ring, (j - 1) & 1);
+      if (active) compute(ring == 0 ? 2 : ring - 1, ring, (j - 1) & 1);
       ring = nxt;
     }
     t += n;

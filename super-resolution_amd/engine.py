@@ -443,6 +443,9 @@ class Plan:
         d.tasks, d.ntasks = dev.data_ptr(), len(tasks)
         d.nslices = nslices if nslices is not None else max(1, _ceil(target_blocks, len(tasks)))
         d.group = group
+        pad = ksize // 2
+        OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        tile_walk = bool(tile_walk or self.wgrad_walk) and ksize == 3 and stride == 1 and OW >= 24
         d.tile_walk = 1 if tile_walk else 0
         if self.deterministic_wgrad:
             assert self._stage_total > 0, "deterministic weight gradients need the plan's staging buffer"
@@ -456,8 +459,6 @@ class Plan:
                         it.nslices = max(it.nslices, d.nslices)
         ops.append(op)
         if isinstance(ops, OpList):
-            pad = ksize // 2
-            OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
             pairs = sum(min(32, e["ld"] - e["ci0"]) * min(32, e["co_n"] - e["co0"])
                         for t in tasks for e in t["sub"].values())
             ltw = 5 if OW >= 24 else (4 if OW >= 12 else 3)
@@ -465,9 +466,16 @@ class Plan:
             tp = 128 if ksize == 1 else ((64 if f else 128) if stride == 1 else (32 if f else 64))
             name = "wgrad_kernel<%s,%d,%d,%d,%d>" % ("float" if f else "bf16", stride,
                                                      5 if ksize == 1 else ltw, ksize, tp)
-            if tile_walk and ksize == 3 and stride == 1 and OW >= 24:
+            if tile_walk:
                 name = "wgrad_walk_kernel<%s,%d>" % ("float" if f else "bf16", tp)
             ops.meta.append((name, 2.0 * B * OH * OW * ksize * ksize * pairs))
+
+    # The column-walk weight-gradient kernel (3x3, stride 1, images at least 24 pixels wide) for every
+    # launch it serves: a third fewer staged activation bytes per tile at the same register budget as
+    # the plain kernel, so it shares a CU with the data-gradient chain just as well.  Config 2, one box,
+    # per step: 9.43 / 9.46 ms with the walk in the last two trunk launches only, 9.28 / 9.33 in every
+    # trunk launch, 9.22 / 9.22 in every launch.  SRX_WGRAD_WALK=0: only where a launch asks for it.
+    wgrad_walk = os.environ.get("SRX_WGRAD_WALK", "1") != "0"
 
     unpack_accumulate = 0    # 1: run_unpack adds into the destination gradients
 

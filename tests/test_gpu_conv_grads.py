@@ -62,6 +62,7 @@ def test_wgrad_full_tensor(case, tdtype, walk):
     dw, db = plan.f32(cout * cin * 9), plan.f32(cout)
     tasks = plan.wgrad_tasks_for_layer(cin, cout, 0, 0, stage_w.data_ptr(), bias_ptr=stage_b.data_ptr())
     ops = E.OpList()
+    plan.wgrad_walk = walk        # walk=False: the plain kernel, whatever the engine's default
     plan.wgrad(ops, (X, 0), (GY, 0), tasks, B, H, W, ksize=3, stride=stride, tile_walk=walk)
     if walk:
         # several slices, so that slices begin in the middle of tile columns too

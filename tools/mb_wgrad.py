@@ -18,7 +18,7 @@ x = torch.rand(16, 3, 64, 64, device=dev) * 2 - 1
 plan.forward(x)
 plan.GY.t.normal_()
 plan.run(plan.bwd_ops); torch.cuda.synchronize()
-idx = [i for i, (n, f) in enumerate(plan.bwd_meta) if n.startswith("wgrad_kernel") and f > 1e11]
+idx = [i for i, (n, f) in enumerate(plan.bwd_meta) if n.startswith("wgrad") and f > 1e11]
 ops = (L.Op * len(idx))(*[plan.bwd_ops[i] for i in idx])
 fl = sum(plan.bwd_meta[i][1] for i in idx)
 plan.run(ops); torch.cuda.synchronize()
