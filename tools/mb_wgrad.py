@@ -13,6 +13,7 @@ import os
 E.Plan.pair_wgrad_tasks = bool(int(os.environ.get("PAIR", "0")))
 E.GeneratorPlan.trunk_wgrad_slices = int(os.environ.get('SLICES', '4'))
 E.GeneratorPlan.trunk_wgrad_rdbs = int(os.environ.get('RDBS', '6'))
+E.GeneratorPlan.trunk_wgrad_target_wgs = int(os.environ.get('TARGET', '256'))
 plan = E.GeneratorPlan(params, 16, 64, 64, torch.bfloat16, need_grad=True)
 x = torch.rand(16, 3, 64, 64, device=dev) * 2 - 1
 plan.forward(x)
