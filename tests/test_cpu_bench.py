@@ -60,7 +60,8 @@ def test_a_failing_rank_stops_the_others_within_seconds(tmp_path, capsys):
     sys.path.insert(0, ROOT)
     import bench
     cmds = _fake_ranks("import time; print('rank0 up', flush=True); time.sleep(120)",
-                       "import sys; sys.stderr.write('boom from rank 1\\n'); sys.exit(3)",
+                       # (dies after rank 0 has had time to start and print, however loaded the machine is)
+                       "import sys, time; time.sleep(1.5); sys.stderr.write('boom from rank 1\\n'); sys.exit(3)",
                        "import time; time.sleep(120)")
     t0 = time.monotonic()
     rc, out0 = bench.supervise_ranks(cmds, rank_timeout=60.0, grace_s=2.0, log_dir=str(tmp_path))
