@@ -27,6 +27,10 @@ CASES = [
     (1, 64, 128, 16, 24, 2),
     (1, 3, 64, 14, 10, 1),
     (1, 64, 32, 136, 130, 1),
+    # fewer rows than a tile has, a single row, one tile column exactly
+    (1, 64, 32, 3, 24, 1),
+    (3, 32, 32, 1, 57, 1),
+    (1, 64, 64, 5, 64, 1),
 ]
 
 
