@@ -946,11 +946,10 @@ class GeneratorPlan(_GenBase):
     # (config 3, one box: 7.57 ms per step with 250 workgroups per launch, 7.08 with 104-156).
     fused_bwd_wgrad_slices = 2
     fused_bwd_wgrad_target_wgs = 128
-    # the last trunk weight-gradient launches run after the data-gradient chain has ended, alone on
-    # the chip, where the column-walk kernel is the faster one (beside the chain it is the slower)
-    # (None: by size — measured best: 2 launches at 64 K pixels per step, 8 from 256 K pixels on,
-    #  where the chain is far ahead of the weight gradients: -0.6 %, -4 % and -5 % per step at
-    #  16 x 64x64, 16 x 128x128 and 64 x 128x128)
+    # With wgrad_walk off (SRX_WGRAD_WALK=0) the column-walk kernel still serves the last trunk
+    # weight-gradient launches, which run after the data-gradient chain has ended, alone on the chip
+    # (None: by size — 2 launches at 64 K pixels per step, 8 from 256 K pixels on).  With wgrad_walk on,
+    # the default, every eligible launch uses it and this setting changes nothing.
     trunk_wgrad_walk_last = None
 
     def __init__(self, params: Dict[str, torch.Tensor], B: int, h: int, w: int, tdtype,
