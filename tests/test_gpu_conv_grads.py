@@ -148,3 +148,27 @@ def test_dense_block_stacked_dgrad_matches_autograd():
     gx = plan.c8_to_nchw((GX, 0), gc)
     torch.cuda.synchronize()
     assert rel_err(gx, ref) < 1e-3
+
+
+def test_column_walk_kernel_is_the_default_where_it_applies():
+    """A plan left to itself takes the column-walk weight-gradient kernel for every 3x3 stride-1 launch
+    on maps at least 24 pixels wide and the whole-tile kernel elsewhere; the descriptor says the same."""
+    E, G, L = pkg("engine"), pkg("esrgan.generator"), pkg("_lib")
+    from helpers import fill_module_
+    assert E.Plan.wgrad_walk is True
+    g = fill_module_(G.GeneratorESRGAN(num_blocks=1), salt=7).cuda()
+    params = {n: p.data for n, p in g.named_parameters()}
+    wide = E.GeneratorPlan(params, 2, 32, 32, torch.bfloat16, num_blocks=1, need_grad=True)
+    narrow = E.GeneratorPlan(params, 2, 16, 16, torch.bfloat16, num_blocks=1, need_grad=True)
+    for plan, trunk_w in ((wide, 32), (narrow, 16)):
+        seen = set()
+        for op, (name, _) in zip(plan.bwd_ops, plan.bwd_meta):
+            if op.kind != L.OP_WGRAD:
+                continue
+            d = op.u.wgrad
+            eligible = d.ksize == 3 and d.stride == 1 and d.W >= 24
+            assert bool(d.tile_walk) == eligible
+            assert name.startswith("wgrad_walk_kernel" if eligible else "wgrad_kernel")
+            seen.add((d.W, bool(d.tile_walk)))
+        assert (trunk_w, trunk_w >= 24) in seen          # the trunk's launches
+        assert (4 * trunk_w, True) in seen               # the layers at HR resolution
