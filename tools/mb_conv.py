@@ -23,6 +23,13 @@ def bench(B, H, W, cin, cout, dt=torch.bfloat16, reps=200, stride=1, distinct=Tr
     us = e0.elapsed_time(e1) * 1e3 / reps
     fl = 2.0 * B * (H // stride) * (W // stride) * 9 * cin * cout
     print(f"B{B} {H}x{W} cin{cin} cout{cout} {str(dt)[6:]}: {us:8.2f} us  {fl / us / 1e6:8.1f} TF/s")
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    bench(64, 128, 128, 192, 64, reps=50)
+    bench(64, 128, 128, 64, 64, reps=50)
+    bench(64, 128, 128, 64, 256, reps=50)
+    bench(16, 256, 256, 64, 256, reps=20)
+    bench(16, 512, 512, 64, 64, reps=20)
+    sys.exit(0)
 for cin in (16, 32, 64, 96, 128, 160, 192):
     bench(16, 64, 64, cin, 32)
 bench(16, 64, 64, 192, 64)
